@@ -1,0 +1,13 @@
+"""vfclik_amd -- MI355X-native batched replacement for vfclik's per-cycle control loop.
+
+Hot path (HIP, gfx950): ``vfclik_amd/csrc/vfik_hip.hip`` behind the C-ABI of ``include/vfik.h``.
+Host side (this package) mirrors the reference's port / handler interface:
+
+    engine          ctypes binding of the C-ABI (fails loudly without the HIP library)
+    chain, robots   kinematic chain descriptions (what the reference hides in ``Lafik(config)``)
+    fields          /param message handling -> field records (scripts/vf:209-293)
+    ports           in-process stand-in for the YARP port/bottle surface the reference uses
+    handlers        src/handlers.py API, batched
+    command_mixer   src/command_mixer.py API, batched
+"""
+__version__ = "0.1.0"
