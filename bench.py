@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the batched control cycle (BASELINE.json metric: 7-DOF IK cycles/s at batch 65 536).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one control cycle of the whole batch = ONE launch of the fused kernel (vfik_step) over
+synthetic inputs that are already resident in HBM.  Workload at every N: BASELINE config C3 per GPU
+(65 536 arms x 7 joints, goal + 8 decay repellers, float32 I/O, float64 arithmetic) -- C4 is exactly
+this with 8 ranks, so scaling is weak and there is no collective on the data path.
+
+Rank 0 prints one JSON line.  `roofline` prices the kernel against HBM with the ALGORITHMIC bytes of
+SURVEY 8d (384 B per cycle at C3); `cpu_baseline` times the CPU oracle (oracle/, the build's port of
+the reference loop -- the reference itself cannot run) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (robot, batch per GPU, obstacles, io dtype, flags, algorithmic bytes per cycle [SURVEY 8d])
+    "C2": ("lwr", 4096, 4, "float64", 0, 512),
+    "C3": ("lwr", 65536, 8, "float32", 0, 384),
+    "C5": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 696),
+}
+
+
+def cpu_baseline(chain, params, w, budget_s=12.0):
+    """CPU oracle (C, OpenMP over arms) on repeated passes over the same batch, ~budget_s seconds."""
+    from oracle import oracle_c
+    threads = oracle_c.max_threads()
+    B = w["q"].shape[0]
+    oracle_c.cycle_batch(chain, params, w["q"][:1024], w["fields"][:1024], w["nfields"][:1024], want=("qdot_out",))
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",))
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s and passes >= 2:
+            break
+    return {"value": passes * B / dt, "unit": "cycles/s", "cores": threads, "kind": "port",
+            "sample": "%d passes over the %d-arm batch in %.1f s, C oracle (oracle/vfik_oracle.c), OpenMP" % (passes, B, dt)}
+
+
+def numpy_loop_rate(chain, params, w, arms=150):
+    """The reference-style per-arm Python/NumPy loop (oracle/vfik_numpy.py), one process."""
+    from oracle import vfik_numpy as vn
+    from vfclik_amd import _abi
+    pd = _abi.params_to_dict(params)
+    cycles = []
+    for b in range(arms):
+        arm = vn.ArmCycle(chain.B, chain.jtype, chain.q_lo, chain.q_hi, pd)
+        arm.set_fields({int(f["id"]): [float(f["force"]), int(f["type"]), f["p"][:_abi.FIELD_NPARAMS[int(f["type"])]].tolist()]
+                        for f in w["fields"][b][: w["nfields"][b]]})
+        cycles.append((arm, w["q"][b].tolist()))
+    t0 = time.perf_counter()
+    for arm, q in cycles:
+        arm.cycle(q)
+    return arms / (time.perf_counter() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from vfclik_amd import _abi, engine, robots, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    robot, B, nobs, io_name, flags, bytes_per_cycle = WORKLOADS[args.workload]
+    io_dtype = np.dtype(io_name)
+    chain = robots.by_name(robot)
+    params = _abi.default_params(flags=flags)
+    w = synth.make_workload(chain, B, nobs, seed=1 + rank, io_dtype=io_dtype.type)  # seeds 1.. for timing
+
+    eng = engine.Engine(chain, B, io_dtype=io_dtype.type, max_slots=nobs, device=local_rank, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    tdt = torch.float32 if io_dtype == np.float32 else torch.float64
+    dev = torch.device("cuda", local_rank)
+    q = torch.from_numpy(w["q"].astype(io_dtype)).to(dev)
+    qdot = torch.zeros(B, chain.n, dtype=tdt, device=dev)
+    stream = torch.cuda.current_stream()
+    eng.use_stream(stream.cuda_stream)
+    io = eng.make_io(q, qdot_out=qdot)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(io)
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        eng.step(io)
+    ev1.record(stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)  # same stream as the launches
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gathered = None
+    if args.gather and world > 1:
+        # optional collation of the per-rank results (NOT part of the control path): one all_gather
+        parts = [torch.empty_like(qdot) for _ in range(world)]
+        dist.all_gather(parts, qdot)
+        gathered = torch.cat(parts)
+
+    if rank == 0:
+        got = qdot.cpu().numpy().astype(np.float64)
+        from oracle import oracle_c  # checker only: accuracy half of the metric + CPU baseline
+        ref = oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",))
+        max_err = float(np.abs(got - ref["qdot_out"]).max())
+        us_per_launch = ev_ms * 1e3 / args.steps
+        achieved = bytes_per_cycle * B / (us_per_launch * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "7-DOF IK cycles/sec (whole node), batch=65536; max |qdot-qdot_ref|",
+            "value": world * B * args.steps / elapsed,
+            "unit": "cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: batch=%d/GPU x %d-DOF %s, goal + %d decay repellers, %s I/O, flags=0x%x"
+                                   % (args.workload, B, chain.n, chain.name, nobs, io_name, flags),
+                       "parallelism": "arm batch sharded over %d GPU(s), no collective" % world,
+                       "lambda": params.lambda_, "launches_per_step": 1},
+            "max_abs_err_rad_s": max_err,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "vfik::cycle_kernel<%s,%d,%s>" % ("float" if io_name == "float32" else "double", chain.n,
+                                                                   "true" if flags & 1 else "false"),
+                         "algorithmic_bytes_per_cycle": bytes_per_cycle, "us_per_launch_hip_events": us_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(chain, params, w)
+            line["cpu_baseline"]["numpy_ref_style_loop_cycles_per_s_1proc"] = numpy_loop_rate(chain, params, w)
+        if gathered is not None:
+            line["config"]["gathered_rows"] = int(gathered.shape[0])
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/* vfik.h -- C-ABI of the MI355X-native batched closed-loop IK path (libvfik_hip.so).
+ *
+ * The reference (arcoslab/vfclik) has no FFI: its per-cycle path is a set of Python processes
+ * (scripts/vf, scripts/nullspace, scripts/debug_jointlimits, src/command_mixer.py inside
+ * scripts/bridge) that exchange YARP bottles.  This header is the boundary a maintainer would bind
+ * (ctypes) to replace the body of those loops for B arms at once.  Each entry
+ * point names the reference code it stands in for (file:line under the reference tree).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch / HIP types in any signature (a HIP stream is
+ *     passed as void*).
+ *   - every function returns 0 on success or a negative VFIK_E_* code; vfik_last_error() gives
+ *     the text for the calling thread.  Bad input is never fatal -- like the reference, which
+ *     logs and ignores malformed bottles (scripts/vf:176-179,204-207,264-266).
+ *   - per-arm numeric trouble (NaN, limit stop, ...) is reported in status[B] (VFIK_ST_*),
+ *     never by failing the call (src/command_mixer.py:71-75 only prints).
+ *   - batch arrays are batch-major: q[B][n], qdot[B][n], pose[B][16], ...  Element type is the
+ *     handle's io dtype (float for 32, double for 64).  Arithmetic is always float64.
+ *   - one host thread per handle; one handle per device (shards are independent).
+ *   - there is no CPU implementation behind this ABI.  Without a GPU vfik_create fails.
+ */
+#ifndef VFIK_H
+#define VFIK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vfik_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFIK_ABI_VERSION 1
+
+enum {
+    VFIK_OK = 0,
+    VFIK_E_ARG = -1,         /* bad argument (size, NULL, range); nothing was changed */
+    VFIK_E_HIP = -2,         /* a HIP runtime call failed */
+    VFIK_E_UNSUPPORTED = -3, /* e.g. a joint count the library was not built for */
+    VFIK_E_STATE = -4        /* call order (chain not set, ...) */
+};
+
+typedef struct vfik_handle vfik_handle;
+
+int vfik_abi_version(void);
+const char* vfik_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never initialises a context) */
+int vfik_device_count(void);
+/* joint counts this build has kernels for, as a bit mask (bit n set = n joints supported) */
+uint32_t vfik_supported_joints(void);
+
+/* One handle = the state that the reference spreads over one vf, one nullspace, one
+ * debug_jointlimits and one bridge/CommandMixer process PER ARM, for `batch` arms on one GPU:
+ * field sets (vf:145), sticky tool frames (vf:154), IK weights, nullspace sign state
+ * (nullspace:91-92), mixer weights and last commands (command_mixer.py:39-44).
+ * io_dtype: 32 or 64.  max_slots: capacity of the per-arm field list in device slots
+ * (a repeller takes 1, hemisphere/funnel 2, an extra attractor 3; the first attractor is free). */
+vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, int batch);
+void vfik_destroy(vfik_handle* h);
+
+/* Run on the caller's HIP stream (e.g. torch's current stream) instead of the handle's own.
+ * The pointer is used as given: NULL selects the device's default (null) stream. */
+int vfik_set_stream(vfik_handle* h, void* hip_stream);
+
+/* Lafik(config) (vf:153, nullspace:60, debug_jointlimits:56): chain geometry + joint limits. */
+int vfik_set_chain(vfik_handle* h, const vfik_chain* chain);
+
+/* speedScale (/max_vel, vf:197-207), 't'/'j' weights (/weight, vf:295-309), nullspace gain and
+ * look-ahead (nullspace:62,121), mixer weights (/bridge/weight, command_mixer.py:48-53), bridge
+ * max_vel (bridge:612-623), feature flags.  Range checks of the ports are done by the host layer. */
+int vfik_set_params(vfik_handle* h, const vfik_params* p);
+
+/* /tool (vf:321-326): 16 doubles row-major, shared by the batch (per_arm = 0) or tool16[B][16]. */
+int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
+
+/* Field sets of arms [first_arm, first_arm + n_arms): the result of the add/remove bookkeeping of
+ * vf:209-275 -- fields[n_arms][max_fields] in the reference's parameter layouts, counts[n_arms].
+ * Packing (ascending id; lowest-id attractor -> goal block) happens here, on the host, only when a
+ * message arrived, exactly when the reference rebuilds totalVF (vf:276-293). */
+int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field* fields,
+                    int max_fields, const int32_t* counts);
+
+/* Last command of mixer channel 2..5 (jointcmd, mechanismcmd, xtra1cmd, xtra2cmd; bridge:593-596)
+ * for the whole batch: host array cmd[B][n] in the io dtype, or NULL to zero the channel, which is
+ * also what the watchdog does after guard_time of silence (command_mixer.py:64-66). */
+int vfik_set_ext_cmd(vfik_handle* h, int channel, const void* cmd_host);
+
+/* Forget the nullspace sign memory (sig = 1, lastvec = 0; nullspace:91-92). */
+int vfik_reset_state(vfik_handle* h);
+
+/* Buffers of one control cycle.  NULL = not wanted / not supplied. */
+typedef struct vfik_io {
+    const void* q;            /* in  [B][n]   /qIn, /nullspace/qin, /debug/qin (vf:312, nullspace:162) */
+    const void* null_control; /* in  [B][4]   /nullspace/control (nullspace:169-173); NULL = zeros */
+    void* qdot_vf;            /* out [B][n]   /vectorField/qdotOut (vf:462-466) */
+    void* qdot_null;          /* out [B][n]   /nullspace/qdotout (nullspace:180-184) */
+    void* qdot_out;           /* out [B][n]   mixed (+limited) command (bridge:626); = qdot_vf without the mixer */
+    void* pose;               /* out [B][16]  /pose (vf:341) */
+    void* pose_nt;            /* out [B][16]  /pose_no_tool (vf:342) */
+    void* v6;                 /* out [B][6]   field twist before RefPoint (vf:346-347; /vector_out) */
+    void* qdist;              /* out [B][n]   distToCenter (debug_jointlimits:65-67), not x100 */
+    int32_t* status;          /* out [B]      VFIK_ST_* */
+} vfik_io;
+
+/* One control cycle for the whole batch -- the loop bodies of vf:311-466, nullspace:162-184,
+ * debug_jointlimits:61-73 and command_mixer.py:78-82 (+ bridge:188-195) in ONE kernel launch.
+ * Device pointers; asynchronous on the handle's stream. */
+int vfik_step(vfik_handle* h, const vfik_io* io);
+/* Same with host pointers: copies in, runs, copies out, synchronises. */
+int vfik_step_host(vfik_handle* h, const vfik_io* io);
+int vfik_sync(vfik_handle* h);
+
+/* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
+ * host weights[K], device out[B][n].  Bit-exact with the reference's left-to-right sum. */
+int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out);
+
+/* Device memory for hosts that do not bring their own allocator (torch tensors work as well). */
+void* vfik_dev_alloc(vfik_handle* h, size_t bytes);
+int vfik_dev_free(vfik_handle* h, void* p);
+int vfik_memcpy_h2d(vfik_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int vfik_memcpy_d2h(vfik_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+
+/* hipEvent timing of `steps` back-to-back vfik_step launches on the handle's stream, after
+ * `warmup` untimed ones: total elapsed ms -> *ms_total.  (bench.py: kernel time on the stream the
+ * kernel really runs on.) */
+int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, float* ms_total);
+
+/* introspection for tests / DESIGN.md: slots in use, bytes of device state */
+int vfik_slots_in_use(vfik_handle* h);
+size_t vfik_device_bytes(vfik_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFIK_H */

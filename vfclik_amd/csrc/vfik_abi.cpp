@@ -1,0 +1,521 @@
+// vfik_abi.cpp -- host side of the C-ABI declared in include/vfik.h: handle, device state, field
+// packing, launches.  Compiled by hipcc into libvfik_hip.so together with vfik_kernel.hip.
+// There is no CPU execution path in this file: every compute entry point launches a HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vfik.h"
+#include "vfik_kernel.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(VFIK_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// number of device slots a field of this type occupies (goal block excluded)
+int slots_of(int type) {
+    switch (type) {
+        case VFIK_FIELD_NULL: return 0;
+        case VFIK_FIELD_REPELLER: return 1;
+        case VFIK_FIELD_HEMISPHERE: return 2;
+        case VFIK_FIELD_FUNNEL: return 2;
+        case VFIK_FIELD_ATTRACTOR: return 3;
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+struct vfik_handle {
+    int device = 0, io_dtype = 32, n = 0, max_slots = 0, B = 0, block = 256;
+    size_t esz = 4;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    vfik_chain chain{};
+    bool chain_set = false;
+    vfik_params params{};
+    // device state
+    void* d_goal = nullptr;    // [18][B]
+    void* d_slots = nullptr;   // [S][8][B]
+    void* d_tool = nullptr;    // [12] or [12][B]
+    int tool_per_arm = 0;
+    void* d_ext = nullptr;     // [4][B][n], allocated on first use
+    double* d_lastvec = nullptr;  // [n][B]
+    int* d_sig = nullptr;      // [B]
+    double* d_mixw = nullptr;  // [16]
+    size_t dev_bytes = 0;
+    // host bookkeeping
+    std::vector<int> slots_per_arm;
+    int slots_used = 0;
+    // scratch for vfik_step_host
+    struct Scratch { void* p = nullptr; size_t bytes = 0; };
+    Scratch sc[10];
+};
+
+namespace {
+
+int dev_alloc(vfik_handle* h, void** p, size_t bytes, bool zero) {
+    HIP_TRY(hipMalloc(p, bytes));
+    h->dev_bytes += bytes;
+    if (zero) HIP_TRY(hipMemsetAsync(*p, 0, bytes, h->stream));
+    return VFIK_OK;
+}
+
+template <typename T>
+void put(std::vector<char>& buf, size_t idx, double v) {
+    reinterpret_cast<T*>(buf.data())[idx] = static_cast<T>(v);
+}
+
+// Pack the field sets of n_arms arms into SoA staging rows (row r, arm j -> r * n_arms + j).
+template <typename T>
+void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
+                 std::vector<char>& goal, std::vector<char>& slots, std::vector<int>& used) {
+    goal.assign((size_t)18 * n_arms * sizeof(T), 0);
+    slots.assign((size_t)S * 8 * n_arms * sizeof(T), 0);
+    std::vector<int> order;
+    for (int j = 0; j < n_arms; ++j) {
+        const vfik_field* f = fields + (size_t)j * max_fields;
+        order.resize(counts[j]);
+        for (int k = 0; k < counts[j]; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f[a].id < f[b].id; });
+        bool have_goal = false;
+        int m = 0;
+        for (int k : order) {
+            const vfik_field& fd = f[k];
+            if (fd.type == VFIK_FIELD_NULL) continue;
+            if (fd.type == VFIK_FIELD_ATTRACTOR && !have_goal) {
+                have_goal = true;
+                for (int e = 0; e < 15; ++e) put<T>(goal, (size_t)e * n_arms + j, fd.p[e]);
+                put<T>(goal, (size_t)15 * n_arms + j, 1.0);  // "goal present"
+                put<T>(goal, (size_t)16 * n_arms + j, fd.p[16]);
+                put<T>(goal, (size_t)17 * n_arms + j, fd.force);
+                continue;
+            }
+            const int ns = slots_of(fd.type);
+            auto at = [&](int slot, int e) { return ((size_t)(m + slot) * 8 + e) * n_arms + j; };
+            for (int e = 0; e < 6; ++e) put<T>(slots, at(0, e), fd.p[e]);
+            put<T>(slots, at(0, 6), fd.force);
+            put<T>(slots, at(0, 7), (double)fd.type);
+            for (int c = 1; c < ns; ++c) {
+                for (int e = 0; e < 6; ++e) {
+                    const int pi = 6 * c + e;
+                    put<T>(slots, at(c, e), pi < VFIK_MAX_PARAMS ? fd.p[pi] : 0.0);
+                }
+                put<T>(slots, at(c, 7), -1.0);
+            }
+            m += ns;
+        }
+        used[j] = m;
+    }
+}
+
+template <int NJ>
+void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs<NJ>& a) {
+    std::memset(&a, 0, sizeof a);
+    a.B = h->B;
+    a.slots_used = h->slots_used;
+    a.flags = h->params.flags;
+    a.tool_per_arm = h->tool_per_arm;
+    a.q = io->q;
+    a.goal = h->d_goal;
+    a.slots = h->d_slots;
+    a.tool = h->d_tool;
+    a.null_control = io->null_control;
+    a.ext = h->d_ext;
+    a.lastvec = h->d_lastvec;
+    a.sig = h->d_sig;
+    a.qdot_vf = io->qdot_vf;
+    a.qdot_null = io->qdot_null;
+    a.qdot_out = io->qdot_out;
+    a.pose = io->pose;
+    a.pose_nt = io->pose_nt;
+    a.v6 = io->v6;
+    a.qdist = io->qdist;
+    a.status = io->status;
+    for (int i = 0; i <= NJ; ++i) std::memcpy(a.CB[i], h->chain.B[i], sizeof a.CB[i]);
+    for (int i = 0; i < NJ; ++i) {
+        a.q_lo[i] = h->chain.q_lo[i];
+        a.q_hi[i] = h->chain.q_hi[i];
+        if (h->chain.jtype[i] == 1) a.prismatic_mask |= 1u << i;
+        a.wq[i] = h->params.wq[i];
+    }
+    const vfik_params& p = h->params;
+    a.speed = p.speed_scale;
+    a.lambda2 = p.lambda * p.lambda;
+    a.rot_slow = p.rot_slowdown;
+    a.null_gain = p.null_gain;
+    a.lookahead = p.lookahead;
+    a.jl_gain = p.jl_gain;
+    a.max_vel = p.max_vel;
+    for (int i = 0; i < 6; ++i) a.wy[i] = p.wy[i];
+    for (int i = 0; i < VFIK_MIX_CHANNELS; ++i) a.mix_w[i] = p.mix_w[i];
+}
+
+int check_handle(const vfik_handle* h) {
+    if (!h) return fail(VFIK_E_ARG, "null handle");
+    return VFIK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vfik_abi_version(void) { return VFIK_ABI_VERSION; }
+
+const char* vfik_last_error(void) { return g_err.c_str(); }
+
+int vfik_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint32_t vfik_supported_joints(void) { return vfik::supported_joints_mask(); }
+
+vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, int batch) {
+    if (io_dtype != 32 && io_dtype != 64) { fail(VFIK_E_ARG, "io_dtype must be 32 or 64, got %d", io_dtype); return nullptr; }
+    if (n_joints < 1 || n_joints > VFIK_MAX_JOINTS || !((vfik::supported_joints_mask() >> n_joints) & 1u)) {
+        fail(VFIK_E_UNSUPPORTED, "no kernel built for %d joints (mask 0x%x)", n_joints, vfik::supported_joints_mask());
+        return nullptr;
+    }
+    if (batch < 1 || max_slots < 0 || max_slots > 4096) { fail(VFIK_E_ARG, "bad batch %d / max_slots %d", batch, max_slots); return nullptr; }
+    int ndev = vfik_device_count();
+    if (device < 0 || device >= ndev) {
+        fail(VFIK_E_HIP, "device %d not available (%d HIP devices visible); this library has no CPU path", device, ndev);
+        return nullptr;
+    }
+    vfik_handle* h = new vfik_handle();
+    h->device = device; h->io_dtype = io_dtype; h->n = n_joints; h->max_slots = max_slots; h->B = batch;
+    h->esz = io_dtype == 32 ? 4 : 8;
+    if (const char* e = std::getenv("VFIK_BLOCK")) {
+        int b = std::atoi(e);
+        if (b == 64 || b == 128 || b == 256) h->block = b;
+    }
+    auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
+    if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    const size_t B = batch;
+    if (dev_alloc(h, &h->d_goal, 18 * B * h->esz, true)) return bail("alloc goal");
+    if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 8 * B * h->esz, true)) return bail("alloc slots");
+    if (dev_alloc(h, &h->d_tool, 12 * h->esz, true)) return bail("alloc tool");
+    if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)n_joints * B * sizeof(double), true)) return bail("alloc lastvec");
+    if (dev_alloc(h, (void**)&h->d_sig, B * sizeof(int), false)) return bail("alloc sig");
+    if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
+    h->slots_per_arm.assign(B, 0);
+    // defaults: identity tool (vf:154), sig = 1 (nullspace:91), reference default parameters
+    const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (vfik_set_tool(h, ident, 0) != VFIK_OK) return bail("set_tool");
+    if (vfik_reset_state(h) != VFIK_OK) return bail("reset_state");
+    vfik_params p{};
+    p.speed_scale = 1.0; p.lambda = 0.1; p.rot_slowdown = 0.3; p.null_gain = 0.5; p.lookahead = 0.3;
+    p.jl_gain = 0.5; p.max_vel = 1.0;
+    for (double& w : p.wy) w = 1.0;
+    for (double& w : p.wq) w = 1.0;
+    p.mix_w[0] = p.mix_w[1] = 1.0;
+    h->params = p;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail("sync");
+    return h;
+}
+
+void vfik_destroy(vfik_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int vfik_set_stream(vfik_handle* h, void* hip_stream) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) HIP_TRY(hipStreamDestroy(h->stream));
+    // the caller's stream is used as given; NULL is HIP's default (null) stream of the device,
+    // which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+    return VFIK_OK;
+}
+
+int vfik_set_chain(vfik_handle* h, const vfik_chain* c) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!c) return fail(VFIK_E_ARG, "null chain");
+    if (c->n != h->n) return fail(VFIK_E_ARG, "chain has %d joints, handle was created for %d", c->n, h->n);
+    for (int i = 0; i < c->n; ++i) {
+        if (c->jtype[i] != 0 && c->jtype[i] != 1) return fail(VFIK_E_ARG, "joint %d: unknown type %d", i, c->jtype[i]);
+        if (!(c->q_hi[i] > c->q_lo[i])) return fail(VFIK_E_ARG, "joint %d: q_hi must exceed q_lo", i);
+    }
+    for (int i = 0; i <= c->n; ++i)
+        for (int k = 0; k < 12; ++k)
+            if (!std::isfinite(c->B[i][k])) return fail(VFIK_E_ARG, "chain transform %d has a non-finite entry", i);
+    h->chain = *c;
+    h->chain_set = true;
+    return VFIK_OK;
+}
+
+int vfik_set_params(vfik_handle* h, const vfik_params* p) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!p) return fail(VFIK_E_ARG, "null params");
+    if (!(p->lambda >= 0.0) || !(p->speed_scale >= 0.0) || !(p->max_vel >= 0.0) || !std::isfinite(p->lambda))
+        return fail(VFIK_E_ARG, "lambda, speed_scale and max_vel must be finite and >= 0");
+    if ((p->flags & VFIK_F_JOINT_LIMIT_TASK) && !(p->flags & VFIK_F_NULLSPACE))
+        return fail(VFIK_E_ARG, "VFIK_F_JOINT_LIMIT_TASK needs VFIK_F_NULLSPACE");
+    h->params = *p;
+    return VFIK_OK;
+}
+
+int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!tool16) return fail(VFIK_E_ARG, "null tool");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = per_arm ? h->B : 1;
+    std::vector<char> buf(12 * B * h->esz);
+    for (size_t b = 0; b < B; ++b)
+        for (int k = 0; k < 12; ++k) {  // rows 0..2 of the 4x4 -> SoA [12][B]
+            const double v = tool16[b * 16 + k];
+            if (h->io_dtype == 32) put<float>(buf, k * B + b, v); else put<double>(buf, k * B + b, v);
+        }
+    if (per_arm != h->tool_per_arm) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_tool) { HIP_TRY(hipFree(h->d_tool)); h->d_tool = nullptr; }
+        if (dev_alloc(h, &h->d_tool, buf.size(), false)) return VFIK_E_HIP;
+        h->tool_per_arm = per_arm ? 1 : 0;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_tool, buf.data(), buf.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field* fields, int max_fields,
+                    const int32_t* counts) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!fields || !counts) return fail(VFIK_E_ARG, "null fields / counts");
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    if (max_fields < 0) return fail(VFIK_E_ARG, "negative max_fields");
+    // validate everything before touching device state
+    for (int j = 0; j < n_arms; ++j) {
+        if (counts[j] < 0 || counts[j] > max_fields) return fail(VFIK_E_ARG, "arm %d: count %d outside [0, %d]", first_arm + j, counts[j], max_fields);
+        int need = 0;
+        bool goal = false;
+        for (int k = 0; k < counts[j]; ++k) {
+            const vfik_field& fd = fields[(size_t)j * max_fields + k];
+            const int ns = slots_of(fd.type);
+            if (ns < 0) return fail(VFIK_E_ARG, "arm %d field %d: unknown type %d", first_arm + j, fd.id, fd.type);
+            if (fd.type == VFIK_FIELD_ATTRACTOR && !goal) { goal = true; continue; }
+            need += ns;
+        }
+        if (need > h->max_slots) return fail(VFIK_E_ARG, "arm %d needs %d slots, handle capacity is %d", first_arm + j, need, h->max_slots);
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<char> goal, slots;
+    std::vector<int> used(n_arms);
+    const int S = h->max_slots;
+    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, used);
+    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, used);
+    const size_t w = (size_t)n_arms * h->esz, pitch = (size_t)h->B * h->esz;
+    char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * h->esz;
+    HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 18, hipMemcpyHostToDevice, h->stream));
+    if (S > 0) {
+        char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * h->esz;
+        HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int j = 0; j < n_arms; ++j) h->slots_per_arm[first_arm + j] = used[j];
+    h->slots_used = *std::max_element(h->slots_per_arm.begin(), h->slots_per_arm.end());
+    return VFIK_OK;
+}
+
+int vfik_set_ext_cmd(vfik_handle* h, int channel, const void* cmd_host) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (channel < 2 || channel >= VFIK_MIX_CHANNELS) return fail(VFIK_E_ARG, "channel %d: only 2..%d are external", channel, VFIK_MIX_CHANNELS - 1);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t chan = (size_t)h->B * h->n * h->esz;
+    if (!h->d_ext) {
+        if (!cmd_host) return VFIK_OK;  // zeroing a channel that was never set
+        if (dev_alloc(h, &h->d_ext, chan * (VFIK_MIX_CHANNELS - 2), true)) return VFIK_E_HIP;
+    }
+    char* dst = static_cast<char*>(h->d_ext) + chan * (channel - 2);
+    if (cmd_host) HIP_TRY(hipMemcpyAsync(dst, cmd_host, chan, hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(hipMemsetAsync(dst, 0, chan, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_reset_state(vfik_handle* h) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<int> ones(h->B, 1);
+    HIP_TRY(hipMemsetAsync(h->d_lastvec, 0, (size_t)h->n * h->B * sizeof(double), h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_sig, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_step(vfik_handle* h, const vfik_io* io) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!io || !io->q) return fail(VFIK_E_ARG, "vfik_step needs io->q");
+    if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    hipError_t e = hipErrorInvalidValue;
+    switch (h->n) {
+#define X(NJ)                                                              \
+    case NJ: {                                                             \
+        vfik::KArgs<NJ> a;                                                 \
+        fill_kargs<NJ>(h, io, a);                                          \
+        e = vfik::launch_cycle(h->io_dtype, NJ, &a, h->B, h->block, h->stream); \
+        break;                                                             \
+    }
+        VFIK_NJ_LIST
+#undef X
+        default: return fail(VFIK_E_UNSUPPORTED, "no kernel for %d joints", h->n);
+    }
+    if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return VFIK_OK;
+}
+
+int vfik_sync(vfik_handle* h) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_step_host(vfik_handle* h, const vfik_io* io) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!io || !io->q) return fail(VFIK_E_ARG, "vfik_step_host needs io->q");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = h->B, n = h->n, e = h->esz;
+    const void* hin[2] = {io->q, io->null_control};
+    const size_t bin[2] = {B * n * e, B * VFIK_NULL_CONTROLS * e};
+    void* hout[8] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status};
+    const size_t bout[8] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t)};
+    auto need = [&](int i, size_t bytes) -> void* {
+        auto& s = h->sc[i];
+        if (s.bytes < bytes) {
+            if (s.p) (void)hipFree(s.p);
+            s.p = nullptr; s.bytes = 0;
+            if (hipMalloc(&s.p, bytes) != hipSuccess) return nullptr;
+            s.bytes = bytes;
+        }
+        return s.p;
+    };
+    void* din[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i)
+        if (hin[i]) {
+            din[i] = need(i, bin[i]);
+            if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+            HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->stream));
+        }
+    void* dout[8];
+    for (int i = 0; i < 8; ++i) {
+        dout[i] = hout[i] ? need(2 + i, bout[i]) : nullptr;
+        if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+    }
+    vfik_io d{};
+    d.q = din[0]; d.null_control = din[1];
+    d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
+    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]);
+    int rc = vfik_step(h, &d);
+    if (rc != VFIK_OK) return rc;
+    for (int i = 0; i < 8; ++i)
+        if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!cmds || !weights || !out || K < 1 || K > 16) return fail(VFIK_E_ARG, "vfik_mix: bad arguments (K=%d)", K);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_mixw, weights, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const long count = (long)h->B * h->n;
+    hipError_t e = vfik::launch_mix(h->io_dtype, cmds, h->d_mixw, K, count, count, out, h->stream);
+    if (e != hipSuccess) return fail(VFIK_E_HIP, "mix launch: %s", hipGetErrorString(e));
+    return VFIK_OK;
+}
+
+void* vfik_dev_alloc(vfik_handle* h, size_t bytes) {
+    if (!h || bytes == 0) { fail(VFIK_E_ARG, "vfik_dev_alloc: bad arguments"); return nullptr; }
+    void* p = nullptr;
+    if (hipSetDevice(h->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { fail(VFIK_E_HIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+int vfik_dev_free(vfik_handle* h, void* p) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipFree(p));
+    return VFIK_OK;
+}
+
+int vfik_memcpy_h2d(vfik_handle* h, void* dst, const void* src, size_t bytes) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_memcpy_d2h(vfik_handle* h, void* dst, const void* src, size_t bytes) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, float* ms_total) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!ms_total || steps < 1 || warmup < 0) return fail(VFIK_E_ARG, "vfik_time_steps: bad arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int i = 0; i < warmup; ++i) {
+        int rc = vfik_step(h, io);
+        if (rc != VFIK_OK) return rc;
+    }
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, h->stream));
+    for (int i = 0; i < steps; ++i) {
+        int rc = vfik_step(h, io);
+        if (rc != VFIK_OK) { (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); return rc; }
+    }
+    HIP_TRY(hipEventRecord(t1, h->stream));
+    HIP_TRY(hipEventSynchronize(t1));
+    HIP_TRY(hipEventElapsedTime(ms_total, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return VFIK_OK;
+}
+
+int vfik_slots_in_use(vfik_handle* h) { return h ? h->slots_used : VFIK_E_ARG; }
+
+size_t vfik_device_bytes(vfik_handle* h) { return h ? h->dev_bytes : 0; }
+
+}  // extern "C"

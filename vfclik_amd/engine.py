@@ -1,0 +1,251 @@
+"""ctypes binding of libvfik_hip.so (include/vfik.h) -- the only compute path of this package.
+
+``Engine`` owns one ``vfik_handle``: the batched state of the reference's per-arm vf / nullspace /
+debug_jointlimits / bridge-mixer processes on one GPU.  It fails loudly when the HIP library is
+missing or no GPU is visible; nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from .chain import Chain
+
+
+class VfikError(RuntimeError):
+    pass
+
+
+class IO(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("null_control", C.c_void_p), ("qdot_vf", C.c_void_p), ("qdot_null", C.c_void_p),
+                ("qdot_out", C.c_void_p), ("pose", C.c_void_p), ("pose_nt", C.c_void_p), ("v6", C.c_void_p),
+                ("qdist", C.c_void_p), ("status", C.c_void_p)]
+
+
+_OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n"}
+_lib = None
+
+
+def load_library(path=None):
+    """Load libvfik_hip.so and declare the prototypes of include/vfik.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("VFIK_HIP_LIB", _abi.HIP_LIB_PATH)
+    try:
+        # torch ships its own libamdhip64; let it load first so that this process holds ONE HIP
+        # runtime (loading /opt/rocm's copy first makes a later torch.cuda init fail)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(path):
+        raise VfikError("HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    H = C.c_void_p
+    protos = {
+        "vfik_abi_version": (C.c_int, []),
+        "vfik_last_error": (C.c_char_p, []),
+        "vfik_device_count": (C.c_int, []),
+        "vfik_supported_joints": (C.c_uint32, []),
+        "vfik_create": (H, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "vfik_destroy": (None, [H]),
+        "vfik_set_stream": (C.c_int, [H, C.c_void_p]),
+        "vfik_set_chain": (C.c_int, [H, C.POINTER(_abi.Chain)]),
+        "vfik_set_params": (C.c_int, [H, C.POINTER(_abi.Params)]),
+        "vfik_set_tool": (C.c_int, [H, C.c_void_p, C.c_int]),
+        "vfik_set_fields": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_set_ext_cmd": (C.c_int, [H, C.c_int, C.c_void_p]),
+        "vfik_reset_state": (C.c_int, [H]),
+        "vfik_step": (C.c_int, [H, C.POINTER(IO)]),
+        "vfik_step_host": (C.c_int, [H, C.POINTER(IO)]),
+        "vfik_sync": (C.c_int, [H]),
+        "vfik_mix": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_dev_alloc": (C.c_void_p, [H, C.c_size_t]),
+        "vfik_dev_free": (C.c_int, [H, C.c_void_p]),
+        "vfik_memcpy_h2d": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t]),
+        "vfik_memcpy_d2h": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t]),
+        "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
+        "vfik_slots_in_use": (C.c_int, [H]),
+        "vfik_device_bytes": (C.c_size_t, [H]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vfik_abi_version() != 1:
+        raise VfikError("ABI version mismatch")
+    if path == _abi.HIP_LIB_PATH or _lib is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(x):
+    """Device / host address of a torch tensor, numpy array or raw int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()  # torch.Tensor
+
+
+class Engine:
+    def __init__(self, chain, batch, io_dtype=np.float32, max_slots=16, device=0, params=None):
+        if not isinstance(chain, Chain):
+            raise TypeError("chain must be a vfclik_amd.chain.Chain")
+        self.lib = load_library()
+        self.chain = chain
+        self.n = chain.n
+        self.batch = int(batch)
+        self.io_dtype = np.dtype(io_dtype)
+        if self.io_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("io_dtype must be float32 or float64")
+        self.max_slots = int(max_slots)
+        self.device = int(device)
+        bits = 32 if self.io_dtype == np.float32 else 64
+        self.h = self.lib.vfik_create(self.device, bits, self.n, self.max_slots, self.batch)
+        if not self.h:
+            raise VfikError("vfik_create: " + self.lib.vfik_last_error().decode())
+        self._chk(self.lib.vfik_set_chain(self.h, C.byref(chain.to_struct())))
+        self.params = params if params is not None else _abi.default_params()
+        self._chk(self.lib.vfik_set_params(self.h, C.byref(self.params)))
+        self._torch_out = {}
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise VfikError("vfik error %d: %s" % (rc, self.lib.vfik_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vfik_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream_ptr):
+        """Launch on the caller's HIP stream (``torch.cuda.current_stream().cuda_stream``)."""
+        self._chk(self.lib.vfik_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # -- slow-changing state (event-driven in the reference) --------------------------------------
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            k = "lambda_" if k == "lambda" else k
+            if k in ("wy", "wq", "mix_w"):
+                arr = getattr(self.params, k)
+                for i, x in enumerate(v):
+                    arr[i] = float(x)
+            else:
+                setattr(self.params, k, v)
+        self._chk(self.lib.vfik_set_params(self.h, C.byref(self.params)))
+
+    def set_tool(self, tool16, per_arm=False):
+        t = np.ascontiguousarray(tool16, dtype=np.float64)
+        if t.size != (16 * self.batch if per_arm else 16):
+            raise ValueError("tool must hold 16 doubles%s" % (" per arm" if per_arm else ""))
+        self._chk(self.lib.vfik_set_tool(self.h, t.ctypes.data, 1 if per_arm else 0))
+
+    def set_fields(self, fields, counts, first_arm=0):
+        f = np.ascontiguousarray(fields, dtype=_abi.FIELD_DTYPE)
+        if f.ndim != 2:
+            raise ValueError("fields must be (n_arms, max_fields)")
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        self._chk(self.lib.vfik_set_fields(self.h, int(first_arm), f.shape[0], f.ctypes.data, f.shape[1], c.ctypes.data))
+
+    def set_ext_cmd(self, channel, cmd):
+        if cmd is None:
+            self._chk(self.lib.vfik_set_ext_cmd(self.h, int(channel), None))
+            return
+        a = np.ascontiguousarray(cmd, dtype=self.io_dtype)
+        if a.shape != (self.batch, self.n):
+            raise ValueError("cmd must be (batch, n)")
+        self._chk(self.lib.vfik_set_ext_cmd(self.h, int(channel), a.ctypes.data))
+
+    def reset_state(self):
+        self._chk(self.lib.vfik_reset_state(self.h))
+
+    @property
+    def slots_in_use(self):
+        return self.lib.vfik_slots_in_use(self.h)
+
+    @property
+    def device_bytes(self):
+        return self.lib.vfik_device_bytes(self.h)
+
+    # -- one control cycle -----------------------------------------------------------------------
+    def _shape(self, key):
+        d = _OUT_SHAPES[key]
+        return (self.batch, self.n if d == "n" else d)
+
+    def step_host(self, q, null_control=None, want=("qdot_out",)):
+        """Host arrays in, host arrays out (copies + sync inside the library)."""
+        q = np.ascontiguousarray(q, dtype=self.io_dtype)
+        if q.shape != (self.batch, self.n):
+            raise ValueError("q must be (%d, %d), got %s" % (self.batch, self.n, q.shape))
+        io = IO()
+        io.q = q.ctypes.data
+        keep = [q]
+        if null_control is not None:
+            nc = np.ascontiguousarray(null_control, dtype=self.io_dtype)
+            if nc.shape != (self.batch, _abi.NULL_CONTROLS):
+                raise ValueError("null_control must be (batch, 4)")
+            io.null_control = nc.ctypes.data
+            keep.append(nc)
+        out = {}
+        for k in want:
+            if k == "status":
+                out[k] = np.zeros(self.batch, dtype=np.int32)
+            else:
+                out[k] = np.zeros(self._shape(k), dtype=self.io_dtype)
+            setattr(io, k, out[k].ctypes.data)
+        self._chk(self.lib.vfik_step_host(self.h, C.byref(io)))
+        return out
+
+    def make_io(self, q, null_control=None, **outs):
+        """IO block from device pointers (torch tensors on this device, or raw addresses)."""
+        io = IO()
+        io.q = _ptr(q)
+        io.null_control = _ptr(null_control)
+        for k, v in outs.items():
+            setattr(io, k, _ptr(v))
+        return io
+
+    def step(self, io):
+        """Asynchronous launch on the handle's stream; ``io`` from :meth:`make_io`."""
+        self._chk(self.lib.vfik_step(self.h, C.byref(io)))
+
+    def sync(self):
+        self._chk(self.lib.vfik_sync(self.h))
+
+    def time_steps(self, io, warmup, steps):
+        ms = C.c_float(0.0)
+        self._chk(self.lib.vfik_time_steps(self.h, C.byref(io), int(warmup), int(steps), C.byref(ms)))
+        return float(ms.value)
+
+    # -- device memory without torch -------------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = self.lib.vfik_dev_alloc(self.h, int(nbytes))
+        if not p:
+            raise VfikError("vfik_dev_alloc: " + self.lib.vfik_last_error().decode())
+        return p
+
+    def dev_free(self, p):
+        self._chk(self.lib.vfik_dev_free(self.h, C.c_void_p(p)))
+
+    def h2d(self, dst, arr):
+        a = np.ascontiguousarray(arr)
+        self._chk(self.lib.vfik_memcpy_h2d(self.h, C.c_void_p(dst), a.ctypes.data, a.nbytes))
+
+    def d2h(self, arr, src):
+        self._chk(self.lib.vfik_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src), arr.nbytes))
+
+    def mix(self, cmds_dev, weights, out_dev):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._chk(self.lib.vfik_mix(self.h, C.c_void_p(_ptr(cmds_dev)), w.ctypes.data, len(w), C.c_void_p(_ptr(out_dev))))
