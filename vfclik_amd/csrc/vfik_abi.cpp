@@ -50,7 +50,7 @@ int slots_of(int type) {
 }  // namespace
 
 struct vfik_handle {
-    int device = 0, io_dtype = 32, n = 0, max_slots = 0, B = 0, block = 256;
+    int device = 0, io_dtype = 32, n = 0, max_slots = 0, B = 0, Bpad = 0, block = 64;
     size_t esz = 4;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -58,18 +58,23 @@ struct vfik_handle {
     bool chain_set = false;
     vfik_params params{};
     // device state
-    void* d_goal = nullptr;    // [18][B]
-    void* d_slots = nullptr;   // [S][8][B]
-    void* d_tool = nullptr;    // [12] or [12][B]
+    void* d_goal = nullptr;    // 4 quad planes
+    void* d_slots = nullptr;   // 2*S quad planes
+    void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
+    double tool_shared[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     int tool_per_arm = 0;
     void* d_ext = nullptr;     // [4][B][n], allocated on first use
     double* d_lastvec = nullptr;  // [n][B]
     int* d_sig = nullptr;      // [B]
     double* d_mixw = nullptr;  // [16]
+    unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
     size_t dev_bytes = 0;
     // host bookkeeping
     std::vector<int> slots_per_arm;
+    std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
+    int fast_order = 0;
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     Scratch sc[10];
@@ -89,12 +94,13 @@ void put(std::vector<char>& buf, size_t idx, double v) {
     reinterpret_cast<T*>(buf.data())[idx] = static_cast<T>(v);
 }
 
-// Pack the field sets of n_arms arms into SoA staging rows (row r, arm j -> r * n_arms + j).
+// Pack the field sets of n_arms arms into quad-plane staging images (plane P, arm j, component c ->
+// (P * n_arms + j) * 4 + c): goal = 4 planes, slots = 2*S planes (vfik_kernel.h).
 template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
                  std::vector<char>& goal, std::vector<char>& slots, std::vector<int>& used) {
-    goal.assign((size_t)18 * n_arms * sizeof(T), 0);
-    slots.assign((size_t)S * 8 * n_arms * sizeof(T), 0);
+    goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
+    slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
     std::vector<int> order;
     for (int j = 0; j < n_arms; ++j) {
         const vfik_field* f = fields + (size_t)j * max_fields;
@@ -103,19 +109,20 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f[a].id < f[b].id; });
         bool have_goal = false;
         int m = 0;
+        auto gq = [&](int e) { return ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3); };
         for (int k : order) {
             const vfik_field& fd = f[k];
             if (fd.type == VFIK_FIELD_NULL) continue;
             if (fd.type == VFIK_FIELD_ATTRACTOR && !have_goal) {
                 have_goal = true;
-                for (int e = 0; e < 15; ++e) put<T>(goal, (size_t)e * n_arms + j, fd.p[e]);
-                put<T>(goal, (size_t)15 * n_arms + j, 1.0);  // "goal present"
-                put<T>(goal, (size_t)16 * n_arms + j, fd.p[16]);
-                put<T>(goal, (size_t)17 * n_arms + j, fd.force);
+                for (int e = 0; e < 12; ++e) put<T>(goal, gq(e), fd.p[e]);
+                put<T>(goal, gq(12), 1.0);  // "goal present"
+                put<T>(goal, gq(13), fd.p[16]);
+                put<T>(goal, gq(14), fd.force);
                 continue;
             }
             const int ns = slots_of(fd.type);
-            auto at = [&](int slot, int e) { return ((size_t)(m + slot) * 8 + e) * n_arms + j; };
+            auto at = [&](int slot, int e) { return ((size_t)(2 * (m + slot) + (e >> 2)) * n_arms + j) * 4 + (e & 3); };
             for (int e = 0; e < 6; ++e) put<T>(slots, at(0, e), fd.p[e]);
             put<T>(slots, at(0, 6), fd.force);
             put<T>(slots, at(0, 7), (double)fd.type);
@@ -132,13 +139,14 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
     }
 }
 
-template <int NJ>
-void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs<NJ>& a) {
+void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     std::memset(&a, 0, sizeof a);
     a.B = h->B;
+    a.Bpad = h->Bpad;
     a.slots_used = h->slots_used;
+    a.fast_order = h->fast_order;
     a.flags = h->params.flags;
-    a.tool_per_arm = h->tool_per_arm;
+    a.tool_stride = h->tool_per_arm ? h->Bpad : 0;
     a.q = io->q;
     a.goal = h->d_goal;
     a.slots = h->d_slots;
@@ -155,23 +163,38 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs<NJ>& a) {
     a.v6 = io->v6;
     a.qdist = io->qdist;
     a.status = io->status;
-    for (int i = 0; i <= NJ; ++i) std::memcpy(a.CB[i], h->chain.B[i], sizeof a.CB[i]);
-    for (int i = 0; i < NJ; ++i) {
-        a.q_lo[i] = h->chain.q_lo[i];
-        a.q_hi[i] = h->chain.q_hi[i];
-        if (h->chain.jtype[i] == 1) a.prismatic_mask |= 1u << i;
-        a.wq[i] = h->params.wq[i];
+    a.stamps = h->d_stamps;
+    a.kc = h->d_kconst;
+}
+
+// rewrite the device copy of the batch constants (chain + parameters); rare, synchronous
+int upload_kconst(vfik_handle* h) {
+    if (!h->chain_set) return VFIK_OK;
+    std::vector<char> img(vfik::kconst_bytes(h->n));
+    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared);
+    if (!(err < 1e-9)) return fail(VFIK_E_ARG, "chain: a fixed transform is not a rigid motion (DH recomposition error %.3e)", err);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_kconst, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+// which arms qualify for the kernel's straight-line repeller path
+int classify_arm(const vfik_field* f, int count) {
+    int order = -1;
+    bool goal = false;
+    for (int k = 0; k < count; ++k) {
+        const vfik_field& fd = f[k];
+        if (fd.type == VFIK_FIELD_NULL) continue;
+        if (fd.type == VFIK_FIELD_ATTRACTOR && !goal) { goal = true; continue; }
+        if (fd.type != VFIK_FIELD_REPELLER) return -2;
+        const double o = fd.p[5];
+        const int n = (int)o;
+        if (!((double)n == o) || n < 0 || n >= 128) return -2;
+        if (order >= 0 && n != order) return -2;
+        order = n;
     }
-    const vfik_params& p = h->params;
-    a.speed = p.speed_scale;
-    a.lambda2 = p.lambda * p.lambda;
-    a.rot_slow = p.rot_slowdown;
-    a.null_gain = p.null_gain;
-    a.lookahead = p.lookahead;
-    a.jl_gain = p.jl_gain;
-    a.max_vel = p.max_vel;
-    for (int i = 0; i < 6; ++i) a.wy[i] = p.wy[i];
-    for (int i = 0; i < VFIK_MIX_CHANNELS; ++i) a.mix_w[i] = p.mix_w[i];
+    return order;
 }
 
 int check_handle(const vfik_handle* h) {
@@ -212,22 +235,26 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     h->esz = io_dtype == 32 ? 4 : 8;
     if (const char* e = std::getenv("VFIK_BLOCK")) {
         int b = std::atoi(e);
-        if (b == 64 || b == 128 || b == 256) h->block = b;
+        if (b == 64 || b == 128 || b == 192) h->block = b;  // LDS staging: <= 3 waves (51 KB each for float64 I/O)
     }
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
     const size_t B = batch;
-    if (dev_alloc(h, &h->d_goal, 18 * B * h->esz, true)) return bail("alloc goal");
-    if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 8 * B * h->esz, true)) return bail("alloc slots");
-    if (dev_alloc(h, &h->d_tool, 12 * h->esz, true)) return bail("alloc tool");
+    h->Bpad = (batch + 63) / 64 * 64;
+    const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
+    if (dev_alloc(h, &h->d_goal, 4 * quad_plane, true)) return bail("alloc goal");
+    if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane, true)) return bail("alloc slots");  // >= 1 slot: the prefetch reads slot 0
     if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)n_joints * B * sizeof(double), true)) return bail("alloc lastvec");
     if (dev_alloc(h, (void**)&h->d_sig, B * sizeof(int), false)) return bail("alloc sig");
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
+    if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints), true)) return bail("alloc kconst");
     h->slots_per_arm.assign(B, 0);
+    h->arm_order.assign(B, -1);
+#ifdef VFIK_STAMPS
+    if (dev_alloc(h, (void**)&h->d_stamps, ((B + 63) / 64) * 8 * sizeof(unsigned long long), true)) return bail("alloc stamps");
+#endif
     // defaults: identity tool (vf:154), sig = 1 (nullspace:91), reference default parameters
-    const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if (vfik_set_tool(h, ident, 0) != VFIK_OK) return bail("set_tool");
     if (vfik_reset_state(h) != VFIK_OK) return bail("reset_state");
     vfik_params p{};
     p.speed_scale = 1.0; p.lambda = 0.1; p.rot_slowdown = 0.3; p.null_gain = 0.5; p.lookahead = 0.3;
@@ -244,7 +271,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -274,9 +301,13 @@ int vfik_set_chain(vfik_handle* h, const vfik_chain* c) {
     for (int i = 0; i <= c->n; ++i)
         for (int k = 0; k < 12; ++k)
             if (!std::isfinite(c->B[i][k])) return fail(VFIK_E_ARG, "chain transform %d has a non-finite entry", i);
+    const vfik_chain saved = h->chain;
+    const bool was_set = h->chain_set;
     h->chain = *c;
     h->chain_set = true;
-    return VFIK_OK;
+    const int rc = upload_kconst(h);
+    if (rc != VFIK_OK) { h->chain = saved; h->chain_set = was_set; }
+    return rc;
 }
 
 int vfik_set_params(vfik_handle* h, const vfik_params* p) {
@@ -287,28 +318,30 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     if ((p->flags & VFIK_F_JOINT_LIMIT_TASK) && !(p->flags & VFIK_F_NULLSPACE))
         return fail(VFIK_E_ARG, "VFIK_F_JOINT_LIMIT_TASK needs VFIK_F_NULLSPACE");
     h->params = *p;
-    return VFIK_OK;
+    return upload_kconst(h);
 }
 
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!tool16) return fail(VFIK_E_ARG, "null tool");
     HIP_TRY(hipSetDevice(h->device));
-    const size_t B = per_arm ? h->B : 1;
-    std::vector<char> buf(12 * B * h->esz);
-    for (size_t b = 0; b < B; ++b)
-        for (int k = 0; k < 12; ++k) {  // rows 0..2 of the 4x4 -> SoA [12][B]
-            const double v = tool16[b * 16 + k];
-            if (h->io_dtype == 32) put<float>(buf, k * B + b, v); else put<double>(buf, k * B + b, v);
-        }
-    if (per_arm != h->tool_per_arm) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->d_tool) { HIP_TRY(hipFree(h->d_tool)); h->d_tool = nullptr; }
-        if (dev_alloc(h, &h->d_tool, buf.size(), false)) return VFIK_E_HIP;
-        h->tool_per_arm = per_arm ? 1 : 0;
+    if (!per_arm) {  // one sticky tool frame for the batch: lives with the other shared constants
+        for (int k = 0; k < 12; ++k) h->tool_shared[k] = tool16[k];
+        h->tool_per_arm = 0;
+        return upload_kconst(h);
     }
+    const size_t B = h->B, Bp = h->Bpad;
+    std::vector<char> buf(3 * Bp * 4 * h->esz, 0);
+    for (size_t b = 0; b < B; ++b)
+        for (int k = 0; k < 12; ++k) {  // rows 0..2 of the 4x4 -> 3 quad planes
+            const double v = tool16[b * 16 + k];
+            const size_t idx = ((size_t)(k >> 2) * Bp + b) * 4 + (k & 3);
+            if (h->io_dtype == 32) put<float>(buf, idx, v); else put<double>(buf, idx, v);
+        }
+    if (!h->d_tool && dev_alloc(h, &h->d_tool, buf.size(), false)) return VFIK_E_HIP;
     HIP_TRY(hipMemcpyAsync(h->d_tool, buf.data(), buf.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->tool_per_arm = 1;
     return VFIK_OK;
 }
 
@@ -338,16 +371,26 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     const int S = h->max_slots;
     if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, used);
     else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, used);
-    const size_t w = (size_t)n_arms * h->esz, pitch = (size_t)h->B * h->esz;
-    char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * h->esz;
-    HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 18, hipMemcpyHostToDevice, h->stream));
+    const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
+    char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
+    HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 4, hipMemcpyHostToDevice, h->stream));
     if (S > 0) {
-        char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * h->esz;
-        HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 8, hipMemcpyHostToDevice, h->stream));
+        char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * qb;
+        HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int j = 0; j < n_arms; ++j) h->slots_per_arm[first_arm + j] = used[j];
+    for (int j = 0; j < n_arms; ++j) {
+        h->slots_per_arm[first_arm + j] = used[j];
+        h->arm_order[first_arm + j] = classify_arm(fields + (size_t)j * max_fields, counts[j]);
+    }
     h->slots_used = *std::max_element(h->slots_per_arm.begin(), h->slots_per_arm.end());
+    int fo = -1;
+    bool general = false;
+    for (int o : h->arm_order) {
+        if (o == -2 || (o >= 0 && fo >= 0 && o != fo)) { general = true; break; }
+        if (o >= 0) fo = o;
+    }
+    h->fast_order = general ? -1 : (fo < 0 ? 0 : fo);
     return VFIK_OK;
 }
 
@@ -382,19 +425,9 @@ int vfik_step(vfik_handle* h, const vfik_io* io) {
     if (!io || !io->q) return fail(VFIK_E_ARG, "vfik_step needs io->q");
     if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
     HIP_TRY(hipSetDevice(h->device));
-    hipError_t e = hipErrorInvalidValue;
-    switch (h->n) {
-#define X(NJ)                                                              \
-    case NJ: {                                                             \
-        vfik::KArgs<NJ> a;                                                 \
-        fill_kargs<NJ>(h, io, a);                                          \
-        e = vfik::launch_cycle(h->io_dtype, NJ, &a, h->B, h->block, h->stream); \
-        break;                                                             \
-    }
-        VFIK_NJ_LIST
-#undef X
-        default: return fail(VFIK_E_UNSUPPORTED, "no kernel for %d joints", h->n);
-    }
+    vfik::KArgs a;
+    fill_kargs(h, io, a);
+    hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, h->stream);
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VFIK_OK;
 }
@@ -513,6 +546,16 @@ int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, fl
     (void)hipEventDestroy(t1);
     return VFIK_OK;
 }
+
+#ifdef VFIK_STAMPS
+// diagnostic build: copy the per-wave section stamps ([waves][8]) to the host
+int vfik_debug_read_stamps(vfik_handle* h, unsigned long long* dst) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dst, h->d_stamps, (size_t)((h->B + 63) / 64) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return VFIK_OK;
+}
+#endif
 
 int vfik_slots_in_use(vfik_handle* h) { return h ? h->slots_used : VFIK_E_ARG; }
 

@@ -13,21 +13,53 @@
 
 namespace vfik {
 
-// Device data layout (DESIGN.md "Data layout in HBM").  T = io dtype (float | double), Bp = batch.
-//   q, qdot_*, qdist      [Bp][n]    batch-major (the reference's bottles: n doubles per arm)
-//   pose, pose_nt         [Bp][16]
-//   goal                  [18][Bp]   SoA: frame16 (element 15 = "goal present" flag), slow-down, force
-//   slots                 [S][8][Bp] SoA: p0..p5, force, type   (type -1 = continuation of the
-//                                    previous slot: p6..p11 / p12..p16; type 0 = empty)
-//   tool                  [12] shared or [12][Bp]
-//   lastvec               [n][Bp] double, sig [Bp] int   (nullspace:91-92 for the unique basis vector)
-//   ext                   [4][Bp][n] last commands of mixer channels 2..5
+// Device data layout (DESIGN.md "Data layout in HBM").  T = io dtype (float | double), B = batch,
+// Bpad = B rounded up to 64.  A "quad" is T[4] (16 or 32 bytes); a quad PLANE is Bpad quads, one per
+// arm, so that the 64 lanes of a wave read 1 KiB (2 KiB) of contiguous memory with one (two)
+// 16-byte-per-lane request(s).
+//   q, qdot_*, qdist      [B][n]      batch-major (the reference's bottles: n doubles per arm)
+//   pose, pose_nt         [B][16]
+//   goal                  4 planes    frame rows 0,1,2 | (present, slow-down, force, -)
+//   slots                 2S planes   slot m = planes 2m, 2m+1 = (p0 p1 p2 p3 | p4 p5 force type);
+//                                     type -1 = continuation of the previous slot (p6..p11 / p12..p16),
+//                                     type 0 = empty
+//   tool (per-arm only)   3 planes    frame rows 0,1,2 (a shared tool lives in KConst)
+//   lastvec               [n][B] double, sig [B] int   (nullspace:91-92 for the unique basis vector)
+//   ext                   [4][B][n]   last commands of mixer channels 2..5
+// Batch-shared constants: chain geometry, limits and parameters.  They live in DEVICE memory (one
+// copy per handle, rewritten only by vfik_set_chain / vfik_set_params) and are read through the
+// scalar cache; the kernarg block stays small.  Measured: with the 2.3 KB of constants inside the
+// kernarg segment every batch of s_loads was a long-latency fetch in the middle of the kinematics.
 template <int NJ>
+struct KConst {
+    // chain in Denavit-Hartenberg form, derived on the host from the z-normal form of vfik_chain
+    // (vfik_kernel.hip: dh_from_chain).  T_ee = base * prod_i [ Screw_z(q_i) Tx(a_i) Rx(alpha_i) ] * Screw_z(tail)
+    double base[12];      // B[0], row-major 3x4
+    struct DH { double off, coff, soff, d, a, ca, sa, pad; } dh[NJ];
+    //   revolute : angle = q + off, displacement = d      prismatic : angle = atan2(soff, coff), displacement = q + d
+    double tail_c, tail_s, tail_e;  // trailing z-screw of the last fixed transform
+    double q_lo[NJ];
+    double q_hi[NJ];
+    double q_mid[NJ];     // (lo + hi) / 2
+    double inv_half[NJ];  // 2 / (hi - lo)
+    double jl_k[NJ];      // jl_gain / half^2
+    double wq[NJ];
+    double wy[6];
+    double mix_w[VFIK_MIX_CHANNELS];
+    double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
+    double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
+    unsigned prismatic_mask;
+    unsigned pad0;
+};
+
 struct KArgs {
     int B;
+    int Bpad;         // B rounded up to 64: pitch of the quad planes
     int slots_used;
+    int fast_order;   // >= 0: every used slot of every arm is a decay repeller (or empty) with this integer
+                      // decay order (what object_feeder sends for point obstacles); -1: general path
     unsigned flags;
-    int tool_per_arm;
+    int tool_stride;  // 0: one tool for the batch (KConst::tool); else per-arm tool quads ([3][Bpad])
     const void* q;
     const void* goal;
     const void* slots;
@@ -44,22 +76,19 @@ struct KArgs {
     void* v6;
     void* qdist;
     int* status;
-    // chain (z-normal form) and limits
-    double CB[NJ + 1][12];
-    double q_lo[NJ];
-    double q_hi[NJ];
-    unsigned prismatic_mask;
-    unsigned pad0;
-    // parameters
-    double speed, lambda2, rot_slow, null_gain, lookahead, jl_gain, max_vel;
-    double wy[6];
-    double wq[NJ];
-    double mix_w[VFIK_MIX_CHANNELS];
+    unsigned long long* stamps;  // diagnostic builds only (-DVFIK_STAMPS): [waves][8] s_memtime values
+    const void* kc;              // KConst<n> in device memory
 };
+
+// size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest
+// recomposition error of the DH conversion (the caller refuses a chain above 1e-9)
+size_t kconst_bytes(int nj);
+// fill a host image of KConst<nj> at dst
+double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12);
 
 // Type-erased launchers (implemented in vfik_kernel.hip).  kargs points to a KArgs<nj>.
 uint32_t supported_joints_mask();
-hipError_t launch_cycle(int io_dtype, int nj, const void* kargs, int B, int block, hipStream_t stream);
+hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream);
 hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K, long count, long chan_stride,
                       void* out, hipStream_t stream);
 

@@ -15,6 +15,9 @@
 // Arithmetic is float64 whatever the io dtype (DESIGN.md "Precision").
 #include "vfik_kernel.h"
 
+#include <cmath>
+#include <cstring>
+
 namespace vfik {
 namespace {
 
@@ -22,7 +25,40 @@ constexpr double EPS_LEN = 1e-12;  // lengths below this are zero (unit vector :
 constexpr double D_FLOOR = 1e-9;   // distance floor inside decay laws
 constexpr double MAG_CAP = 1e6;    // cap of a repeller's magnitude
 
-__device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
+// ------------------------------------------------------------------------------------------------
+// float64 building blocks.  On gfx950 one wave per SIMD issues a float64 FMA about every 5 cycles
+// (8 when dependent), v_rcp/v_rsq_f64 take ~17-20, and the IEEE sequences the compiler emits for
+// `a / b`, sqrt() and sincos() cost ~65, ~90-110 and ~370 cycles (tools/ubench_fp64.hip).  The
+// control cycle needs none of their corner-case handling, so it uses Newton-refined reciprocals and
+// a branch-free sincos that the scheduler can interleave across the independent joints.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double x) {  // 1/x, ~1 ulp, x normal and non-zero
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// sqrt(x) and 1/sqrt(x) together (Goldschmidt from v_rsq_f64).  x = 0 gives (0, large finite).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& root, double& inv) {
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    root = g;
+    inv = h + h;
+}
+
+__device__ __forceinline__ double norm3(double x, double y, double z) {
+    double r, i;
+    sqrt_rsqrt(x * x + y * y + z * z, r, i);
+    return r;
+}
 
 // acc + x*w with the product and the sum rounded separately, as CPython evaluates
 // `result[i] += v[i] * w` (command_mixer.py:81).  HIP's __dmul_rn/__dadd_rn are plain operators that
@@ -33,12 +69,53 @@ __device__ __forceinline__ double mac_unfused(double acc, double x, double w) {
     return acc + prod;
 }
 
+// sin and cos for |x| <= SINCOS_FAST_MAX: Cody-Waite reduction by pi/2 in three parts, then the
+// classic minimax kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos),
+// < 1 ulp.  Joint angles live inside their limits (a few radians); anything larger takes sincos().
+constexpr double SINCOS_FAST_MAX = 1.0e5;
+__device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-k, 6.07710050630396597660e-11, r);
+    r = __builtin_fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double sr = __builtin_fma(z * r, ps, r);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int n = (int)k;
+    const double sv = (n & 1) ? cr : sr, cv = (n & 1) ? sr : cr;
+    s = (n & 2) ? -sv : sv;
+    c = ((n + 1) & 2) ? -cv : cv;
+}
+
+// x^n, n a wave-uniform small non-negative integer: square-and-multiply with scalar control flow
+__device__ __forceinline__ double powi_uniform(double x, int n) {
+    double r = 1.0, b = x;
+    while (n) {
+        if (n & 1) r *= b;
+        n >>= 1;
+        if (n) b *= b;
+    }
+    return r;
+}
+
 // x^order for x > 0.  Decay orders are small integers in every message the reference sends
-// (object_feeder:277,279,302; README.old:75 uses 20), so take the multiply chain when we can and the
-// general pow() only for a fractional order.
+// (object_feeder:277,279,302; README.old:75 uses 20): multiply chain when we can, pow() otherwise.
 __device__ __forceinline__ double pow_order(double x, double order) {
     const int n = (int)order;
-    if ((double)n == order && n >= 0 && n < 128) {
+    const bool isint = (double)n == order && n >= 0 && n < 128;
+    if (__all(isint)) {
+        const int n0 = __builtin_amdgcn_readfirstlane(n);
+        if (__all(n == n0)) return powi_uniform(x, n0);
         double r = 1.0, b = x;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -47,7 +124,7 @@ __device__ __forceinline__ double pow_order(double x, double order) {
         }
         return r;
     }
-    return pow(x, order);
+    return isint ? powi_uniform(x, n) : pow(x, order);
 }
 
 // Rotation vector (base frame) taking R to G: log(G R^T) = KDL diff(R, G).rot.  Returns |r|.
@@ -59,7 +136,8 @@ __device__ double rot_log(const double* R, const double* G, double* r) {
         for (int j = 0; j < 3; ++j) E[3 * i + j] = G[3 * i] * R[3 * j] + G[3 * i + 1] * R[3 * j + 1] + G[3 * i + 2] * R[3 * j + 2];
     const double a0 = 0.5 * (E[7] - E[5]), a1 = 0.5 * (E[2] - E[6]), a2 = 0.5 * (E[3] - E[1]);
     const double c = 0.5 * (E[0] + E[4] + E[8] - 1.0);
-    const double s = norm3(a0, a1, a2);
+    double s, sinv;
+    sqrt_rsqrt(a0 * a0 + a1 * a1 + a2 * a2, s, sinv);
     const double th = atan2(s, c);
     if (s < 1e-4 && c < 0.0) {
         // theta near pi (rare): axis from the symmetric part  c I + (1-c) a a^T
@@ -79,12 +157,12 @@ __device__ double rot_log(const double* R, const double* G, double* r) {
             y = 0.5 * (E[5] + E[7]) / (omc * z);
         }
         if (x * a0 + y * a1 + z * a2 < 0.0) { x = -x; y = -y; z = -z; }
-        const double k = th / norm3(x, y, z);
+        const double k = th / sqrt(x * x + y * y + z * z);
         r[0] = x * k; r[1] = y * k; r[2] = z * k;
         return th;
     }
     if (s < EPS_LEN) { r[0] = r[1] = r[2] = 0.0; return th; }
-    const double k = th / s;
+    const double k = th * sinv;
     r[0] = a0 * k; r[1] = a1 * k; r[2] = a2 * k;
     return th;
 }
@@ -93,177 +171,399 @@ __device__ double rot_log(const double* R, const double* G, double* r) {
 __device__ __forceinline__ void attractor(const double* R, const double* p, const double* GR, const double* Gp,
                                           double slow, double force, double rot_slow, double* tot, double* sc) {
     const double dx = Gp[0] - p[0], dy = Gp[1] - p[1], dz = Gp[2] - p[2];
-    const double D = norm3(dx, dy, dz);
+    double D, Dinv;
+    sqrt_rsqrt(dx * dx + dy * dy + dz * dz, D, Dinv);
     if (D > EPS_LEN) {
-        const double k = force / D;
+        const double k = force * Dinv;
         tot[0] += dx * k; tot[1] += dy * k; tot[2] += dz * k;
     }
     double r[3];
     const double th = rot_log(R, GR, r);
     if (th > EPS_LEN) {
-        const double k = force / th;
+        const double k = force * rcp_nr(th);
         tot[3] += r[0] * k; tot[4] += r[1] * k; tot[5] += r[2] * k;
     }
-    sc[0] *= slow > 0.0 ? fmin(1.0, D / slow) : 1.0;
-    sc[1] *= rot_slow > 0.0 ? fmin(1.0, th / rot_slow) : 1.0;
+    sc[0] *= slow > 0.0 ? fmin(1.0, D * rcp_nr(slow)) : 1.0;
+    sc[1] *= rot_slow > 0.0 ? fmin(1.0, th * rcp_nr(rot_slow)) : 1.0;
 }
 
+// Element e (0..7) of slot m of this lane's arm in the quad-plane layout (vfik_kernel.h): plane
+// 2m + e/4, component e%4.  sq points at plane 0, component 0 of the lane's arm; Q = plane pitch in
+// elements (4 * Bpad).
+template <typename T>
+__device__ __forceinline__ double slot_elem(const T* sq, long Q, int m, int e) {
+    return (double)sq[(long)(2 * m + (e >> 2)) * Q + (e & 3)];
+}
+
+// One field slot of any type, read from memory (the general path: mixed primitive types in a wave,
+// fractional decay orders, more slots than the prefetch window).
+template <typename T>
+__device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const double* pt, double rot_slow, double* tot, double* sc) {
+    const int type = (int)slot_elem(sq, Q, m, 7);
+    if (type <= 0) return;
+    const double p0 = slot_elem(sq, Q, m, 0), p1 = slot_elem(sq, Q, m, 1), p2 = slot_elem(sq, Q, m, 2),
+                 p3 = slot_elem(sq, Q, m, 3), p4 = slot_elem(sq, Q, m, 4), p5 = slot_elem(sq, Q, m, 5),
+                 force = slot_elem(sq, Q, m, 6);
+    if (type == VFIK_FIELD_REPELLER) {  // x y z radius safeDist order
+        const double dx = p0 - pt[0], dy = p1 - pt[1], dz = p2 - pt[2];
+        double D, Dinv;
+        sqrt_rsqrt(dx * dx + dy * dy + dz * dz, D, Dinv);
+        Dinv = D < D_FLOOR ? 1.0 / D_FLOOR : Dinv;
+        const double mag = fmin(pow_order((p3 + p4) * Dinv, p5), MAG_CAP);
+        const double k = force * mag * Dinv;
+        tot[0] += dx * k; tot[1] += dy * k; tot[2] += dz * k;
+    } else if (type == VFIK_FIELD_HEMISPHERE) {  // x y z nx ny nz | safeDist order
+        const double safe = slot_elem(sq, Q, m + 1, 0), order = slot_elem(sq, Q, m + 1, 1);
+        double nn, ninv;
+        sqrt_rsqrt(p3 * p3 + p4 * p4 + p5 * p5, nn, ninv);
+        if (nn > EPS_LEN) {
+            const double h = ((pt[0] - p0) * p3 + (pt[1] - p1) * p4 + (pt[2] - p2) * p5) * ninv;
+            const double mag = fmin(pow_order(safe * rcp_nr(fmax(h, D_FLOOR)), order), MAG_CAP);
+            const double k = -force * mag * ninv;
+            tot[0] += p3 * k; tot[1] += p4 * k; tot[2] += p5 * k;
+        }
+    } else if (type == VFIK_FIELD_FUNNEL) {  // x y z ax ay az | cutAngle angleOrder cutDist distOrder
+        const double cutA = slot_elem(sq, Q, m + 1, 0), ordA = slot_elem(sq, Q, m + 1, 1),
+                     cutD = slot_elem(sq, Q, m + 1, 2), ordD = slot_elem(sq, Q, m + 1, 3);
+        double an, ainv;
+        sqrt_rsqrt(p3 * p3 + p4 * p4 + p5 * p5, an, ainv);
+        if (an > EPS_LEN) {
+            const double ax = p3 * ainv, ay = p4 * ainv, az = p5 * ainv;
+            const double wx = pt[0] - p0, wy = pt[1] - p1, wz = pt[2] - p2;
+            const double along = wx * ax + wy * ay + wz * az;
+            const double ex = wx - along * ax, ey = wy - along * ay, ez = wz - along * az;
+            double P, Pinv, dist, dinv;
+            sqrt_rsqrt(ex * ex + ey * ey + ez * ez, P, Pinv);
+            sqrt_rsqrt(wx * wx + wy * wy + wz * wz, dist, dinv);
+            Pinv = P < D_FLOOR ? 1.0 / D_FLOOR : Pinv;
+            dinv = dist < D_FLOOR ? 1.0 / D_FLOOR : dinv;
+            const double phi = atan2(P, along);
+            const double ga = cutA > 0.0 ? fmin(1.0, pow_order(phi * rcp_nr(cutA), ordA)) : 1.0;
+            const double gd = fmin(1.0, pow_order(cutD * dinv, ordD));
+            const double k = -force * ga * gd * Pinv;
+            tot[0] += ex * k; tot[1] += ey * k; tot[2] += ez * k;
+        }
+    } else if (type == VFIK_FIELD_ATTRACTOR) {  // a second attractor: frame16 + slow over 3 slots
+        double GR[9], Gp[3];
+        GR[0] = p0; GR[1] = p1; GR[2] = p2; Gp[0] = p3; GR[3] = p4; GR[4] = p5;
+        GR[5] = slot_elem(sq, Q, m + 1, 0); Gp[1] = slot_elem(sq, Q, m + 1, 1);
+        GR[6] = slot_elem(sq, Q, m + 1, 2); GR[7] = slot_elem(sq, Q, m + 1, 3); GR[8] = slot_elem(sq, Q, m + 1, 4);
+        Gp[2] = slot_elem(sq, Q, m + 1, 5);
+        attractor(Rt, pt, GR, Gp, slot_elem(sq, Q, m + 2, 4), force, rot_slow, tot, sc);
+    }
+}
+
+constexpr int PRE = 8;  // slots whose loads are issued before the kinematics (prefetch window)
+
+// ------------------------------------------------------------------------------------------------
+// Staging through LDS (direct global -> LDS loads, no VGPR destination).  Every lane's inputs of
+// one cycle are requested at wave start and land in the wave's private LDS region while the
+// kinematics run; the arithmetic waits with counted s_waitcnt vmcnt at the three points where a
+// group of inputs is first needed.  Rows are lane-linear (lane * 16 B or lane * 4 B): conflict-free.
+//   region layout per wave, Q16 = 16-byte sub-planes per quad of T (1 for float, 2 for double):
+//     quad rows  [tool 3 | goal 4 | slots 2*PRE] x Q16 x 1 KiB,  then q: NJ x (sizeof(T)/4) x 256 B
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Stage {
+    static constexpr int Q16 = (int)sizeof(T) / 4;           // 16-B pieces per quad
+    static constexpr int QROWS = (3 + 4 + 2 * PRE) * Q16;    // 1 KiB rows
+    static constexpr int ROW_TOOL = 0, ROW_GOAL = 3 * Q16, ROW_SLOT = 7 * Q16;
+    static constexpr int QBYTES = 4 * (int)sizeof(T);        // bytes of one quad
+    // q is batch-major ([B][n]): a lane's n values are contiguous and travel as 16-byte pieces plus a
+    // remainder of one to three 4-byte pieces (a 12-byte LDS-DMA did not land lane-linear on gfx950)
+    __host__ __device__ static constexpr int qbytes(int nj) { return nj * (int)sizeof(T); }
+    __host__ __device__ static constexpr int q16(int nj) { return qbytes(nj) / 16; }
+    __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
+    __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
+    __host__ __device__ static constexpr int bytes(int nj) { return QROWS * 1024 + qregion(nj); }
+};
+
+// LDS byte address (relative to the q area) of byte b of this lane's q vector
+template <typename T, int NJ>
+__device__ __forceinline__ int q_lds_off(int b, int lane) {
+    constexpr int n16 = Stage<T>::q16(NJ), rem = Stage<T>::qrem(NJ);
+    if (b < n16 * 16) return (b >> 4) * 1024 + lane * 16 + (b & 15);
+    const int rb = b - n16 * 16;
+    (void)rem;
+    return n16 * 1024 + (rb >> 2) * 256 + lane * 4 + (rb & 3);  // remainder: 4-byte pieces
+}
+
+typedef __attribute__((address_space(1))) const void* GPtr;
+typedef __attribute__((address_space(3))) void* LPtr;
+
+// one quad plane: this lane's quad (QBYTES at gsrc) -> rows [row, row + Q16) of the region
+template <typename T>
+__device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int row) {
+    __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + row * 1024), 16, 0, 0);
+    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + (row + 1) * 1024), 16, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void read_quad(const char* region, int row, int lane, double* out) {
+    if (Stage<T>::Q16 == 1) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = *reinterpret_cast<const f4*>(region + row * 1024 + lane * 16);
+        out[0] = (double)v.x; out[1] = (double)v.y; out[2] = (double)v.z; out[3] = (double)v.w;
+    } else {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 lo = *reinterpret_cast<const d2*>(region + row * 1024 + lane * 16);
+        const d2 hi = *reinterpret_cast<const d2*>(region + (row + 1) * 1024 + lane * 16);
+        out[0] = lo.x; out[1] = lo.y; out[2] = hi.x; out[3] = hi.y;
+    }
+}
+
+#define VFIK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// In-kernel section stamps for the diagnostic build only (make stamps; never in libvfik_hip.so).
+#ifdef VFIK_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if ((threadIdx.x & 63) == 0) a.stamps[(long)(arm >> 6) * 8 + (i)] = t_;                    \
+    } while (0)
+#define PIN(x) asm volatile("" : "+v"(x))
+#define PIN_ARR(arr, n)                              \
+    do {                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) PIN((arr)[i_]); \
+    } while (0)
+#else
+#define STAMP(i)
+#define PIN(x)
+#define PIN_ARR(arr, n)
+#endif
+
 template <typename T, int NJ, bool NULLSP>
-__global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
+__global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     const int arm = blockIdx.x * blockDim.x + threadIdx.x;
     if (arm >= a.B) return;
     const long Bs = a.B;
+    // batch constants through the constant address space: always scalar loads
+    typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
+    const KcPtr kc = (KcPtr)(unsigned long long)a.kc;
     int status = 0;
+    STAMP(0);
 
-    // ---------------- q ----------------------------------------------------------------------
-    double q[NJ];
-    {
-        const T* qin = static_cast<const T*>(a.q) + (long)arm * NJ;
+    // ---------------- loads: request everything the cycle needs, straight into LDS ------------
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const int lane = threadIdx.x & 63;
+    char* const region = lds_all + (threadIdx.x >> 6) * Stage<T>::bytes(NJ);
+    const long Bp = a.Bpad;
+    constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
+    const long planeB = Bp * QB;  // bytes of one quad plane
+    if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
+        const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) q[i] = (double)qin[i];
+        for (int k = 0; k < 3; ++k) stage_quad<T>(tg + k * planeB, region, Stage<T>::ROW_TOOL + k * Q16);
     }
+    {
+        const char* qg = static_cast<const char*>(a.q) + (long)arm * NJ * sizeof(T);
+        char* qrow = region + Stage<T>::QROWS * 1024;
+        constexpr int n16 = Stage<T>::q16(NJ), rem = Stage<T>::qrem(NJ);
+#pragma unroll
+        for (int i = 0; i < n16; ++i) __builtin_amdgcn_global_load_lds((GPtr)(qg + i * 16), (LPtr)(qrow + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < rem / 4; ++j)
+            __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + j * 4), (LPtr)(qrow + n16 * 1024 + j * 256), 4, 0, 0);
+    }
+    {
+        const char* gg = static_cast<const char*>(a.goal) + (long)arm * QB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
+    }
+    const int npre = a.slots_used < PRE ? a.slots_used : PRE;
+    {
+        const char* sg = static_cast<const char*>(a.slots) + (long)arm * QB;
+#pragma unroll
+        for (int m = 0; m < PRE; ++m) {
+            // slots past the ones in use re-request slot 0 (cache hit) and are masked below, so the
+            // number of outstanding requests is a compile-time constant for the counted waits
+            const char* sm = sg + (m < npre ? (long)m * 2 * planeB : 0);
+            stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + 2 * m * Q16);
+            stage_quad<T>(sm + planeB, region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16);
+        }
+    }
+    constexpr int N_GOAL = 4 * Q16, N_SLOT = 2 * PRE * Q16;  // requests issued after q
 
+    STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
+    double q[NJ], sn[NJ], cs[NJ];
+    bool big = false;
+    VFIK_WAIT_VM(N_GOAL + N_SLOT);  // tool and q have landed; goal and slots still in flight
+    {
+        const char* qrow = region + Stage<T>::QROWS * 1024;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            if (Q16 == 1) {
+                q[i] = (double)*reinterpret_cast<const float*>(qrow + q_lds_off<T, NJ>(i * 4, lane));
+            } else {
+                const int lo = *reinterpret_cast<const int*>(qrow + q_lds_off<T, NJ>(i * 8, lane));
+                const int hi = *reinterpret_cast<const int*>(qrow + q_lds_off<T, NJ>(i * 8 + 4, lane));
+                q[i] = __hiloint2double(hi, lo);
+            }
+            big = big || !(fabs(q[i]) <= SINCOS_FAST_MAX);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) sincos_fast(q[i] + kc->dh[i].off, sn[i], cs[i]);  // independent: interleaved by the scheduler
+    if (__any(big)) {  // out-of-range or NaN angle somewhere in the wave: full-range sincos
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) sincos(q[i] + kc->dh[i].off, &sn[i], &cs[i]);
+    }
     double R[9], p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R[3 * r + c] = a.CB[0][4 * r + c];
-        p[r] = a.CB[0][4 * r + 3];
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = kc->base[4 * r + c];
+        p[r] = kc->base[4 * r + 3];
     }
     double Jv[NJ][3], Jw[NJ][3];  // first the joint origins / axes, then the Jacobian columns
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
+        // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); 30 flops, 7 scalar constants
         Jw[i][0] = R[2]; Jw[i][1] = R[5]; Jw[i][2] = R[8];
         Jv[i][0] = p[0]; Jv[i][1] = p[1]; Jv[i][2] = p[2];
-        if ((a.prismatic_mask >> i) & 1u) {
-            p[0] += q[i] * R[2]; p[1] += q[i] * R[5]; p[2] += q[i] * R[8];
-        } else {
-            double s, c;
-            sincos(q[i], &s, &c);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double x = R[3 * r], y = R[3 * r + 1];
-                R[3 * r] = c * x + s * y;
-                R[3 * r + 1] = c * y - s * x;
-            }
-        }
-        double Rn[9], pn[3];
+        const bool pris = (kc->prismatic_mask >> i) & 1u;
+        const double ci = pris ? kc->dh[i].coff : cs[i], si = pris ? kc->dh[i].soff : sn[i];
+        const double di = pris ? q[i] + kc->dh[i].d : kc->dh[i].d;
+        const double ai = kc->dh[i].a, ca = kc->dh[i].ca, sa = kc->dh[i].sa;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                Rn[3 * r + c] = R[3 * r] * a.CB[i + 1][c] + R[3 * r + 1] * a.CB[i + 1][4 + c] + R[3 * r + 2] * a.CB[i + 1][8 + c];
-            pn[r] = R[3 * r] * a.CB[i + 1][3] + R[3 * r + 1] * a.CB[i + 1][7] + R[3 * r + 2] * a.CB[i + 1][11] + p[r];
+            const double x = R[3 * r], y = R[3 * r + 1], z = R[3 * r + 2];
+            const double xn = ci * x + si * y, ym = ci * y - si * x;
+            p[r] += di * z + ai * xn;
+            R[3 * r] = xn;
+            R[3 * r + 1] = ca * ym + sa * z;
+            R[3 * r + 2] = ca * z - sa * ym;
         }
+    }
+    {   // trailing z-screw of the last fixed transform
+        const double tc = kc->tail_c, ts = kc->tail_s, te = kc->tail_e;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = pn[k];
+        for (int r = 0; r < 3; ++r) {
+            const double x = R[3 * r], y = R[3 * r + 1];
+            p[r] += te * R[3 * r + 2];
+            R[3 * r] = tc * x + ts * y;
+            R[3 * r + 1] = tc * y - ts * x;
+        }
     }
     // geometric Jacobian at the flange, base frame
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
-        if ((a.prismatic_mask >> i) & 1u) {
-            Jv[i][0] = Jw[i][0]; Jv[i][1] = Jw[i][1]; Jv[i][2] = Jw[i][2];
-            Jw[i][0] = Jw[i][1] = Jw[i][2] = 0.0;
-        } else {
+        {
+            const bool pris = (kc->prismatic_mask >> i) & 1u;
             const double dx = p[0] - Jv[i][0], dy = p[1] - Jv[i][1], dz = p[2] - Jv[i][2];
-            Jv[i][0] = Jw[i][1] * dz - Jw[i][2] * dy;
-            Jv[i][1] = Jw[i][2] * dx - Jw[i][0] * dz;
-            Jv[i][2] = Jw[i][0] * dy - Jw[i][1] * dx;
+            const double cx = Jw[i][1] * dz - Jw[i][2] * dy, cy = Jw[i][2] * dx - Jw[i][0] * dz,
+                         cz = Jw[i][0] * dy - Jw[i][1] * dx;
+            Jv[i][0] = pris ? Jw[i][0] : cx; Jv[i][1] = pris ? Jw[i][1] : cy; Jv[i][2] = pris ? Jw[i][2] : cz;
+            Jw[i][0] = pris ? 0.0 : Jw[i][0]; Jw[i][1] = pris ? 0.0 : Jw[i][1]; Jw[i][2] = pris ? 0.0 : Jw[i][2];
         }
     }
 
+    PIN_ARR(R, 9); PIN_ARR(p, 3);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) { PIN_ARR(Jv[i], 3); PIN_ARR(Jw[i], 3); }
+    STAMP(2);
     // ---------------- A4: tool offset (vf:321-332) --------------------------------------------
-    double Rt[9], pt[3], rr[3];
-    {
-        double tl[12];
-        const T* tp = static_cast<const T*>(a.tool);
-        if (a.tool_per_arm) {
+    double Rt[9], pt[3], rr[3], tl[12];
+    if (a.tool_stride) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) tl[k] = (double)tp[k * Bs + arm];
-        } else {
+        for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lane, tl + 4 * k);
+    } else {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) tl[k] = (double)tp[k];
-        }
+        for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
+    }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Rt[3 * r + c] = R[3 * r] * tl[c] + R[3 * r + 1] * tl[4 + c] + R[3 * r + 2] * tl[8 + c];
-            rr[r] = -(R[3 * r] * tl[3] + R[3 * r + 1] * tl[7] + R[3 * r + 2] * tl[11]);  // p_ee - p_tip
-            pt[r] = p[r] - rr[r];
-        }
+        for (int c = 0; c < 3; ++c) Rt[3 * r + c] = R[3 * r] * tl[c] + R[3 * r + 1] * tl[4 + c] + R[3 * r + 2] * tl[8 + c];
+        rr[r] = -(R[3 * r] * tl[3] + R[3 * r + 1] * tl[7] + R[3 * r + 2] * tl[11]);  // p_ee - p_tip
+        pt[r] = p[r] - rr[r];
     }
 
     // ---------------- A5: vector field at the tool pose (vf:276-293,344-347) -------------------
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
+    VFIK_WAIT_VM(N_SLOT);  // goal block has landed
     {
-        const T* g = static_cast<const T*>(a.goal) + arm;
-        if ((double)g[15 * Bs] != 0.0) {  // goal block = the arm's lowest-id attractor
+        double gq[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lane, gq + 4 * k);
+        if (gq[12] != 0.0) {  // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, -]
             double GR[9], Gp[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) GR[3 * r + c] = (double)g[(4 * r + c) * Bs];
-                Gp[r] = (double)g[(4 * r + 3) * Bs];
+                for (int c = 0; c < 3; ++c) GR[3 * r + c] = gq[4 * r + c];
+                Gp[r] = gq[4 * r + 3];
             }
-            attractor(Rt, pt, GR, Gp, (double)g[16 * Bs], (double)g[17 * Bs], a.rot_slow, tot, sc);
-        }
-        const T* sp = static_cast<const T*>(a.slots) + arm;
-        for (int m = 0; m < a.slots_used; ++m) {
-            const T* s = sp + (long)m * 8 * Bs;
-            const int type = (int)s[7 * Bs];
-            if (type <= 0) continue;
-            const double p0 = (double)s[0], p1 = (double)s[Bs], p2 = (double)s[2 * Bs], p3 = (double)s[3 * Bs],
-                         p4 = (double)s[4 * Bs], p5 = (double)s[5 * Bs], force = (double)s[6 * Bs];
-            if (type == VFIK_FIELD_REPELLER) {  // x y z radius safeDist order
-                const double dx = p0 - pt[0], dy = p1 - pt[1], dz = p2 - pt[2];
-                const double D = fmax(norm3(dx, dy, dz), D_FLOOR);
-                const double mag = fmin(pow_order((p3 + p4) / D, p5), MAG_CAP);
-                const double k = force * mag / D;
-                tot[0] += dx * k; tot[1] += dy * k; tot[2] += dz * k;
-            } else if (type == VFIK_FIELD_HEMISPHERE) {  // x y z nx ny nz | safeDist order
-                const double safe = (double)s[8 * Bs], order = (double)s[9 * Bs];
-                const double nn = norm3(p3, p4, p5);
-                if (nn > EPS_LEN) {
-                    const double h = ((pt[0] - p0) * p3 + (pt[1] - p1) * p4 + (pt[2] - p2) * p5) / nn;
-                    const double mag = fmin(pow_order(safe / fmax(h, D_FLOOR), order), MAG_CAP);
-                    const double k = -force * mag / nn;
-                    tot[0] += p3 * k; tot[1] += p4 * k; tot[2] += p5 * k;
-                }
-            } else if (type == VFIK_FIELD_FUNNEL) {  // x y z ax ay az | cutAngle angleOrder cutDist distOrder
-                const double cutA = (double)s[8 * Bs], ordA = (double)s[9 * Bs], cutD = (double)s[10 * Bs],
-                             ordD = (double)s[11 * Bs];
-                const double an = norm3(p3, p4, p5);
-                if (an > EPS_LEN) {
-                    const double ax = p3 / an, ay = p4 / an, az = p5 / an;
-                    const double wx = pt[0] - p0, wy = pt[1] - p1, wz = pt[2] - p2;
-                    const double along = wx * ax + wy * ay + wz * az;
-                    const double ex = wx - along * ax, ey = wy - along * ay, ez = wz - along * az;
-                    const double P = norm3(ex, ey, ez), dist = norm3(wx, wy, wz);
-                    const double phi = atan2(P, along);
-                    const double ga = cutA > 0.0 ? fmin(1.0, pow_order(phi / cutA, ordA)) : 1.0;
-                    const double gd = fmin(1.0, pow_order(cutD / fmax(dist, D_FLOOR), ordD));
-                    const double k = -force * ga * gd / fmax(P, D_FLOOR);
-                    tot[0] += ex * k; tot[1] += ey * k; tot[2] += ez * k;
-                }
-            } else if (type == VFIK_FIELD_ATTRACTOR) {  // a second attractor: frame16 + slow over 3 slots
-                double GR[9], Gp[3];
-                GR[0] = p0; GR[1] = p1; GR[2] = p2; Gp[0] = p3; GR[3] = p4; GR[4] = p5;
-                GR[5] = (double)s[8 * Bs]; Gp[1] = (double)s[9 * Bs];
-                GR[6] = (double)s[10 * Bs]; GR[7] = (double)s[11 * Bs]; GR[8] = (double)s[12 * Bs];
-                Gp[2] = (double)s[13 * Bs];
-                attractor(Rt, pt, GR, Gp, (double)s[20 * Bs], force, a.rot_slow, tot, sc);
-            }
+            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, tot, sc);
         }
     }
+    PIN_ARR(tot, 6); PIN_ARR(sc, 2);
+    STAMP(3);
+    {
+        // Fast path, decided per wave: every prefetched slot of every lane is a decay repeller (or
+        // empty) and they all share one integer decay order -- what object_feeder produces for point
+        // obstacles (object_feeder:317-334).  Straight-line code, the slots interleave.
+        VFIK_WAIT_VM(0);  // all slots have landed
+        double sv[PRE][8];
+#pragma unroll
+        for (int m = 0; m < PRE; ++m) {
+            read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lane, sv[m]);
+            read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lane, sv[m] + 4);
+        }
+        const T* sq = static_cast<const T*>(a.slots) + (long)arm * 4;
+        const long Qp = Bp * 4;
+        if (a.fast_order >= 0) {
+            // Fast path, decided by the host when the field sets were packed (vfik_set_fields): every
+            // used slot of every arm is a decay repeller with the same integer decay order -- what
+            // object_feeder produces for point obstacles (object_feeder:317-334).  Empty slots carry
+            // force 0.  Straight-line code: the slots interleave in the schedule.
+            const int n0 = a.fast_order;
+            double dx[PRE], dy[PRE], dz[PRE], di[PRE], rb[PRE], rp[PRE];
+#pragma unroll
+            for (int m = 0; m < PRE; ++m) {
+                dx[m] = sv[m][0] - pt[0];
+                dy[m] = sv[m][1] - pt[1];
+                dz[m] = sv[m][2] - pt[2];
+                double D;
+                sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
+                di[m] = D < D_FLOOR ? 1.0 / D_FLOOR : di[m];
+                rb[m] = (sv[m][3] + sv[m][4]) * di[m];
+                rp[m] = 1.0;
+            }
+            for (int e = n0; e; ) {  // square-and-multiply, all slots in lock step
+                if (e & 1) {
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) rp[m] *= rb[m];
+                }
+                e >>= 1;
+                if (e) {
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < PRE; ++m) {
+                const double k = (m < npre ? sv[m][6] : 0.0) * fmin(rp[m], MAG_CAP) * di[m];
+                tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+            }
+        } else {
+            for (int m = 0; m < npre; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
+        }
+        for (int m = PRE; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
+    }
+    PIN_ARR(tot, 6);
+    STAMP(4);
     // normCart + speedScale * scalars (vf:292,346-347)
     double v[3], w[3];
     {
-        const double nt = norm3(tot[0], tot[1], tot[2]), nr = norm3(tot[3], tot[4], tot[5]);
-        const double kt = nt > EPS_LEN ? a.speed * sc[0] / nt : 0.0;
-        const double kr = nr > EPS_LEN ? a.speed * sc[1] / nr : 0.0;
+        double nt, nti, nr, nri;
+        sqrt_rsqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2], nt, nti);
+        sqrt_rsqrt(tot[3] * tot[3] + tot[4] * tot[4] + tot[5] * tot[5], nr, nri);
+        const double kt = nt > EPS_LEN ? kc->speed * sc[0] * nti : 0.0;
+        const double kr = nr > EPS_LEN ? kc->speed * sc[1] * nri : 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { v[k] = tot[k] * kt; w[k] = tot[3 + k] * kr; }
     }
@@ -284,8 +584,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         for (int i = 0; i < NJ; ++i) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                S[i][r] = a.wy[r] * Jv[i][r] * a.wq[i];
-                S[i][3 + r] = a.wy[3 + r] * Jw[i][r] * a.wq[i];
+                S[i][r] = kc->wy[r] * Jv[i][r] * kc->wq[i];
+                S[i][3 + r] = kc->wy[3 + r] * Jw[i][r] * kc->wq[i];
             }
         }
         double A[6][6];
@@ -293,7 +593,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         for (int r = 0; r < 6; ++r)
 #pragma unroll
             for (int c = 0; c <= r; ++c) {
-                double acc = (r == c) ? a.lambda2 : 0.0;
+                double acc = (r == c) ? kc->lambda2 : 0.0;
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) acc += S[i][r] * S[i][c];
                 A[r][c] = acc;
@@ -306,7 +606,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
 #pragma unroll
             for (int k = 0; k < j; ++k) dj -= A[j][k] * A[j][k] * A[k][k];
             A[j][j] = dj;
-            dinv[j] = 1.0 / dj;
+            dinv[j] = rcp_nr(dj);
 #pragma unroll
             for (int i = j + 1; i < 6; ++i) {
                 double t = A[i][j];
@@ -318,7 +618,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = a.wy[i] * tw[i];
+            double t = kc->wy[i] * tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -337,10 +637,12 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
             double acc = 0.0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) acc += S[i][r] * y[r];
-            qv[i] = a.wq[i] * acc;
+            qv[i] = kc->wq[i] * acc;
         }
     }
 
+    PIN_ARR(qv, NJ);
+    STAMP(5);
     // ---------------- A10-A13: nullspace module (nullspace:95-131,162-184) ----------------------
     double qn[NJ];
 #pragma unroll
@@ -373,7 +675,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) n1 += u[i] * u[i];
             const bool keep = n1 > 1e-24 * n0 && n0 > 0.0;
-            const double inv = keep ? 1.0 / sqrt(n1) : 0.0;
+            double n1r, n1i;
+            sqrt_rsqrt(n1, n1r, n1i);
+            const double inv = keep ? n1i : 0.0;
             rank += keep ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) Q[r][i] = u[i] * inv;
@@ -406,7 +710,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
             double nn = 0.0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
-            nn = 1.0 / sqrt(nn);
+            {
+                double nr_, ni_;
+                sqrt_rsqrt(nn, nr_, ni_);
+                nn = ni_;
+            }
             // raw sign as LAPACK's SVD leaves it (first non-negligible component negative; oracle + golden)
             bool found = false;
             double sg = 1.0;
@@ -441,10 +749,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
             double z[NJ];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                const double mid = 0.5 * (a.q_lo[i] + a.q_hi[i]), half = 0.5 * (a.q_hi[i] - a.q_lo[i]);
-                z[i] = -a.jl_gain * (q[i] - mid) / (half * half);
-            }
+            for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 double c = 0.0;
@@ -460,20 +765,22 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         bool stop = false;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
-            const double d = q[i] + a.lookahead * qn[i];
-            stop = stop || d < a.q_lo[i] || d > a.q_hi[i];
+            const double d = q[i] + kc->lookahead * qn[i];
+            stop = stop || d < kc->q_lo[i] || d > kc->q_hi[i];
         }
         if (stop) status |= VFIK_ST_LIMIT_STOP;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * a.null_gain;
+        for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * kc->null_gain;
     }
 
+    PIN_ARR(qn, NJ);
+    STAMP(6);
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
     double qo[NJ];
     if (a.flags & VFIK_F_MIXER) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
-            qo[i] = mac_unfused(mac_unfused(0.0, qv[i], a.mix_w[0]), qn[i], a.mix_w[1]);
+            qo[i] = mac_unfused(mac_unfused(0.0, qv[i], kc->mix_w[0]), qn[i], kc->mix_w[1]);
         }
         if (a.ext) {
             const T* e = static_cast<const T*>(a.ext);
@@ -481,7 +788,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
             for (int ch = 0; ch < VFIK_MIX_CHANNELS - 2; ++ch)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i)
-                    qo[i] = mac_unfused(qo[i], (double)e[((long)ch * Bs + arm) * NJ + i], a.mix_w[2 + ch]);
+                    qo[i] = mac_unfused(qo[i], (double)e[((long)ch * Bs + arm) * NJ + i], kc->mix_w[2 + ch]);
         }
     } else {
 #pragma unroll
@@ -491,8 +798,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
         double lead = 0.0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) lead = fmax(lead, fabs(qo[i]));
-        if (lead > a.max_vel) {
-            const double ratio = a.max_vel / lead;
+        if (lead > kc->max_vel) {
+            const double ratio = kc->max_vel * rcp_nr(lead);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) qo[i] *= ratio;
             status |= VFIK_ST_LIMITED;
@@ -547,12 +854,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs<NJ> a) {
     if (a.qdist) {
         T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            const double mid = 0.5 * (a.q_lo[i] + a.q_hi[i]), half = 0.5 * (a.q_hi[i] - a.q_lo[i]);
-            o[i] = (T)(fabs(q[i] - mid) / half);
-        }
+        for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+
     }
     if (a.status) a.status[arm] = status;
+    STAMP(7);
 }
 
 // CommandMixer.read's weighted sum alone (command_mixer.py:78-82): out = sum_k cmd[k] * w[k], left to
@@ -567,19 +873,108 @@ __global__ void __launch_bounds__(256) mix_kernel(const T* cmds, const double* w
 }
 
 template <typename T, int NJ>
-hipError_t launch_t(const KArgs<NJ>& a, int B, int block, hipStream_t stream) {
-    const dim3 grid((B + block - 1) / block), blk(block);
+hipError_t launch_t(const KArgs& a, int block, hipStream_t stream) {
+    const dim3 grid((a.B + block - 1) / block), blk(block);
+    const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     if (a.flags & VFIK_F_NULLSPACE)
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, true>), grid, blk, 0, stream, a);
+        hipLaunchKernelGGL((cycle_kernel<T, NJ, true>), grid, blk, lds, stream, a);
     else
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, false>), grid, blk, 0, stream, a);
+        hipLaunchKernelGGL((cycle_kernel<T, NJ, false>), grid, blk, lds, stream, a);
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// host: z-normal form -> DH form.  Every fixed transform factors as
+//     B = Rz(theta) Tz(d) Tx(a) Rx(alpha) Rz(phi) Tz(e)          (ZXZ Euler angles + common normal)
+// and the z-screws commute with the joint motions on either side, so the trailing (phi, e) of B[i]
+// joins the leading (theta, d) of B[i+1] and the variable of joint i+1.  B[0] stays general.
+// ------------------------------------------------------------------------------------------------
+struct Screws { double theta, d, a, alpha, phi, e; };
+
+static Screws dh_factor(const double* B) {
+    const double R00 = B[0], R10 = B[4], R02 = B[2], R12 = B[6], R20 = B[8], R21 = B[9], R22 = B[10];
+    const double tx = B[3], ty = B[7], tz = B[11];
+    Screws s{};
+    const double sa = std::sqrt(R02 * R02 + R12 * R12);
+    s.alpha = std::atan2(sa, R22);
+    if (sa > 1e-12) {
+        s.theta = std::atan2(R02, -R12);
+        s.phi = std::atan2(R20, R21);
+        const double ct = std::cos(s.theta), st = std::sin(s.theta);
+        const double ux = ct * tx + st * ty, uy = -st * tx + ct * ty;
+        s.a = ux;
+        s.e = -uy / sa;
+        s.d = tz - s.e * R22;
+    } else {  // consecutive axes parallel (alpha = 0) or anti-parallel (alpha = pi)
+        s.theta = (tx * tx + ty * ty > 1e-24) ? std::atan2(ty, tx) : 0.0;
+        s.a = std::sqrt(tx * tx + ty * ty);
+        s.e = 0.0;
+        s.d = tz;
+        const double g = std::atan2(R10, R00);
+        s.phi = R22 > 0.0 ? g - s.theta : s.theta - g;
+    }
+    return s;
+}
+
+static void mat_mul(const double* A, const double* B, double* C) {  // 3x4 row-major frames
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) C[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j];
+        C[4 * i + 3] = A[4 * i] * B[3] + A[4 * i + 1] * B[7] + A[4 * i + 2] * B[11] + A[4 * i + 3];
+    }
+}
+
+static double dh_recompose_error(const Screws& s, const double* B) {
+    auto rz = [](double t, double d, double* M) { const double c = std::cos(t), sn = std::sin(t); const double m[12] = {c, -sn, 0, 0, sn, c, 0, 0, 0, 0, 1, d}; memcpy(M, m, sizeof m); };
+    auto rx = [](double al, double a, double* M) { const double c = std::cos(al), sn = std::sin(al); const double m[12] = {1, 0, 0, a, 0, c, -sn, 0, 0, sn, c, 0}; memcpy(M, m, sizeof m); };
+    double A[12], X[12], C[12], T1[12], T2[12];
+    rz(s.theta, s.d, A); rx(s.alpha, s.a, X); rz(s.phi, s.e, C);
+    mat_mul(A, X, T1); mat_mul(T1, C, T2);
+    double err = 0.0;
+    for (int k = 0; k < 12; ++k) err = std::fmax(err, std::fabs(T2[k] - B[k]));
+    return err;
+}
+
 template <int NJ>
-hipError_t launch_nj(int io_dtype, const void* kargs, int B, int block, hipStream_t stream) {
-    const KArgs<NJ>& a = *static_cast<const KArgs<NJ>*>(kargs);
-    return io_dtype == 32 ? launch_t<float, NJ>(a, B, block, stream) : launch_t<double, NJ>(a, B, block, stream);
+double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, const double* tool12) {
+    KConst<NJ>& c = *static_cast<KConst<NJ>*>(dst);
+    memset(&c, 0, sizeof c);
+    memcpy(c.base, ch.B[0], sizeof c.base);
+    double phi_prev = 0.0, e_prev = 0.0, worst = 0.0;
+    for (int i = 0; i < NJ; ++i) {
+        const Screws s = dh_factor(ch.B[i + 1]);
+        worst = std::fmax(worst, dh_recompose_error(s, ch.B[i + 1]));
+        const double off = phi_prev + s.theta;
+        c.dh[i].off = off;
+        c.dh[i].coff = std::cos(off);
+        c.dh[i].soff = std::sin(off);
+        c.dh[i].d = e_prev + s.d;
+        c.dh[i].a = s.a;
+        c.dh[i].ca = std::cos(s.alpha);
+        c.dh[i].sa = std::sin(s.alpha);
+        phi_prev = s.phi;
+        e_prev = s.e;
+        const double half = 0.5 * (ch.q_hi[i] - ch.q_lo[i]);
+        c.q_lo[i] = ch.q_lo[i];
+        c.q_hi[i] = ch.q_hi[i];
+        c.q_mid[i] = 0.5 * (ch.q_lo[i] + ch.q_hi[i]);
+        c.inv_half[i] = 1.0 / half;
+        c.jl_k[i] = p.jl_gain / (half * half);
+        c.wq[i] = p.wq[i];
+        if (ch.jtype[i] == 1) c.prismatic_mask |= 1u << i;
+    }
+    c.tail_c = std::cos(phi_prev);
+    c.tail_s = std::sin(phi_prev);
+    c.tail_e = e_prev;
+    for (int i = 0; i < 6; ++i) c.wy[i] = p.wy[i];
+    for (int i = 0; i < VFIK_MIX_CHANNELS; ++i) c.mix_w[i] = p.mix_w[i];
+    for (int k = 0; k < 12; ++k) c.tool[k] = tool12[k];
+    c.speed = p.speed_scale;
+    c.lambda2 = p.lambda * p.lambda;
+    c.rot_slow = p.rot_slowdown;
+    c.null_gain = p.null_gain;
+    c.lookahead = p.lookahead;
+    c.max_vel = p.max_vel;
+    return worst;
 }
 
 }  // namespace
@@ -592,12 +987,30 @@ uint32_t supported_joints_mask() {
     return m;
 }
 
-hipError_t launch_cycle(int io_dtype, int nj, const void* kargs, int B, int block, hipStream_t stream) {
+hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream) {
     switch (nj) {
-#define X(n) case n: return launch_nj<n>(io_dtype, kargs, B, block, stream);
+#define X(n) case n: return io_dtype == 32 ? launch_t<float, n>(kargs, block, stream) : launch_t<double, n>(kargs, block, stream);
         VFIK_NJ_LIST
 #undef X
         default: return hipErrorInvalidValue;
+    }
+}
+
+size_t kconst_bytes(int nj) {
+    switch (nj) {
+#define X(n) case n: return sizeof(KConst<n>);
+        VFIK_NJ_LIST
+#undef X
+        default: return 0;
+    }
+}
+
+double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12) {
+    switch (nj) {
+#define X(n) case n: return kconst_fill_t<n>(dst, chain, p, tool12);
+        VFIK_NJ_LIST
+#undef X
+        default: return 1e300;
     }
 }
 
