@@ -32,7 +32,7 @@ st = np.zeros((nw, 8), dtype=np.uint64)
 eng.lib.vfik_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert eng.lib.vfik_debug_read_stamps(eng.h, st.ctypes.data) == 0
 d = np.diff(st.astype(np.int64), axis=1)
-names = ["issue loads", "wait q+sincos+FK+J", "tool+goal attractor", "slots", "normCart+RefPt+IK", "nullspace", "mixer+stores"]
+names = ["issue loads", "wait for q", "sincos+FK+J", "tool+goal attractor", "slots", "normCart+RefPt+IK", "nullspace+mixer+stores"]
 print("workload", wl, "waves", nw)
 for i in range(7):
     print("  %-22s median %7.0f  p10 %7.0f  p90 %7.0f ticks" % (names[i], np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))

@@ -248,7 +248,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)n_joints * B * sizeof(double), true)) return bail("alloc lastvec");
     if (dev_alloc(h, (void**)&h->d_sig, B * sizeof(int), false)) return bail("alloc sig");
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
-    if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints), true)) return bail("alloc kconst");
+    if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints) + 2048, true)) return bail("alloc kconst");  // + slack: the kinematics block is copied in whole 1-KiB rows
     h->slots_per_arm.assign(B, 0);
     h->arm_order.assign(B, -1);
 #ifdef VFIK_STAMPS

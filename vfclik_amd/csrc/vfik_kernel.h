@@ -32,12 +32,17 @@ namespace vfik {
 // kernarg segment every batch of s_loads was a long-latency fetch in the middle of the kinematics.
 template <int NJ>
 struct KConst {
-    // chain in Denavit-Hartenberg form, derived on the host from the z-normal form of vfik_chain
-    // (vfik_kernel.hip: dh_from_chain).  T_ee = base * prod_i [ Screw_z(q_i) Tx(a_i) Rx(alpha_i) ] * Screw_z(tail)
-    double base[12];      // B[0], row-major 3x4
-    struct DH { double off, coff, soff, d, a, ca, sa, pad; } dh[NJ];
-    //   revolute : angle = q + off, displacement = d      prismatic : angle = atan2(soff, coff), displacement = q + d
-    double tail_c, tail_s, tail_e;  // trailing z-screw of the last fixed transform
+    // ---- kinematics block: copied into LDS by every wave (one or two 1-KiB requests) and read from
+    // there as vector operands.  As scalar (SGPR) operands the ~90 doubles did not fit the 100 SGPRs:
+    // the compiler hoisted every s_load to the top and spilled to VGPR lanes (v_writelane/readlane).
+    // Chain in Denavit-Hartenberg form, derived on the host from the z-normal form of vfik_chain
+    // (vfik_kernel.hip: kconst_fill_t): T_ee = base * prod_i [ Screw_z(q_i) Tx(a_i) Rx(alpha_i) ] * Screw_z(tail)
+    double base[12];  // B[0], row-major 3x4
+    // c = crev*cos(q+off) + cprs, s = crev*sin(q+off) + sprs, displacement = qd*q + d: revolute joints have
+    // (crev, cprs, sprs, qd) = (1, 0, 0, 0), prismatic ones (0, cos off, sin off, 1) -- arithmetic blends
+    struct DH { double off, crev, cprs, sprs, qd, d, a, ca, sa, pad; } dh[NJ];
+    double tail_c, tail_s, tail_e, tail_pad;  // trailing z-screw of the last fixed transform
+    // ---- everything else: read through the scalar cache
     double q_lo[NJ];
     double q_hi[NJ];
     double q_mid[NJ];     // (lo + hi) / 2
@@ -50,6 +55,8 @@ struct KConst {
     double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
     unsigned prismatic_mask;
     unsigned pad0;
+    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
+    static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
 
 struct KArgs {

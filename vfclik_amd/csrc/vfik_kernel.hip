@@ -261,7 +261,8 @@ constexpr int PRE = 8;  // slots whose loads are issued before the kinematics (p
 // kinematics run; the arithmetic waits with counted s_waitcnt vmcnt at the three points where a
 // group of inputs is first needed.  Rows are lane-linear (lane * 16 B or lane * 4 B): conflict-free.
 //   region layout per wave, Q16 = 16-byte sub-planes per quad of T (1 for float, 2 for double):
-//     quad rows  [tool 3 | goal 4 | slots 2*PRE] x Q16 x 1 KiB,  then q: NJ x (sizeof(T)/4) x 256 B
+//     quad rows  [tool 3 | goal 4 | slots 2*PRE] x Q16 x 1 KiB, then q (16-byte and 4-byte pieces),
+//     then the kinematics block of KConst (1-2 KiB)
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Stage {
     static constexpr int Q16 = (int)sizeof(T) / 4;           // 16-B pieces per quad
@@ -274,7 +275,9 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int q16(int nj) { return qbytes(nj) / 16; }
     __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
-    __host__ __device__ static constexpr int bytes(int nj) { return QROWS * 1024 + qregion(nj); }
+    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4) * 8 + 1023) / 1024; }
+    __host__ __device__ static constexpr int kin_off(int nj) { return QROWS * 1024 + qregion(nj); }
+    __host__ __device__ static constexpr int bytes(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }
 };
 
 // LDS byte address (relative to the q area) of byte b of this lane's q vector
@@ -337,7 +340,6 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
 template <typename T, int NJ, bool NULLSP>
 __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     const int arm = blockIdx.x * blockDim.x + threadIdx.x;
-    if (arm >= a.B) return;
     const long Bs = a.B;
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
@@ -352,6 +354,14 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     const long Bp = a.Bpad;
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
     const long planeB = Bp * QB;  // bytes of one quad plane
+    {   // kinematics constants (oldest request: covered by the first wait).  All 64 lanes copy
+        // 16 bytes each, so this comes before the lanes past the end of the batch retire.
+        const char* kg = static_cast<const char*>(a.kc) + lane * 16;
+#pragma unroll
+        for (int r = 0; r < KConst<NJ>::KIN_ROWS; ++r)
+            __builtin_amdgcn_global_load_lds((GPtr)(kg + r * 1024), (LPtr)(region + Stage<T>::kin_off(NJ) + r * 1024), 16, 0, 0);
+    }
+    if (arm >= a.B) return;
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
@@ -390,7 +400,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
     bool big = false;
-    VFIK_WAIT_VM(N_GOAL + N_SLOT);  // tool and q have landed; goal and slots still in flight
+    VFIK_WAIT_VM(N_GOAL + N_SLOT);  // constants, tool and q have landed; goal and slots still in flight
+    const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
+    STAMP(2);
     {
         const char* qrow = region + Stage<T>::QROWS * 1024;
 #pragma unroll
@@ -406,28 +418,28 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) sincos_fast(q[i] + kc->dh[i].off, sn[i], cs[i]);  // independent: interleaved by the scheduler
+    for (int i = 0; i < NJ; ++i) sincos_fast(q[i] + kl->dh[i].off, sn[i], cs[i]);  // independent: interleaved by the scheduler
     if (__any(big)) {  // out-of-range or NaN angle somewhere in the wave: full-range sincos
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) sincos(q[i] + kc->dh[i].off, &sn[i], &cs[i]);
+        for (int i = 0; i < NJ; ++i) sincos(q[i] + kl->dh[i].off, &sn[i], &cs[i]);
     }
     double R[9], p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R[3 * r + c] = kc->base[4 * r + c];
-        p[r] = kc->base[4 * r + 3];
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = kl->base[4 * r + c];
+        p[r] = kl->base[4 * r + 3];
     }
     double Jv[NJ][3], Jw[NJ][3];  // first the joint origins / axes, then the Jacobian columns
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
-        // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); 30 flops, 7 scalar constants
+        // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); ~33 flops, 9 constants from LDS
         Jw[i][0] = R[2]; Jw[i][1] = R[5]; Jw[i][2] = R[8];
         Jv[i][0] = p[0]; Jv[i][1] = p[1]; Jv[i][2] = p[2];
-        const bool pris = (kc->prismatic_mask >> i) & 1u;
-        const double ci = pris ? kc->dh[i].coff : cs[i], si = pris ? kc->dh[i].soff : sn[i];
-        const double di = pris ? q[i] + kc->dh[i].d : kc->dh[i].d;
-        const double ai = kc->dh[i].a, ca = kc->dh[i].ca, sa = kc->dh[i].sa;
+        const double ci = __builtin_fma(kl->dh[i].crev, cs[i], kl->dh[i].cprs);
+        const double si = __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
+        const double di = __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
+        const double ai = kl->dh[i].a, ca = kl->dh[i].ca, sa = kl->dh[i].sa;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double x = R[3 * r], y = R[3 * r + 1], z = R[3 * r + 2];
@@ -439,7 +451,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
     {   // trailing z-screw of the last fixed transform
-        const double tc = kc->tail_c, ts = kc->tail_s, te = kc->tail_e;
+        const double tc = kl->tail_c, ts = kl->tail_s, te = kl->tail_e;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double x = R[3 * r], y = R[3 * r + 1];
@@ -464,7 +476,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     PIN_ARR(R, 9); PIN_ARR(p, 3);
 #pragma unroll
     for (int i = 0; i < NJ; ++i) { PIN_ARR(Jv[i], 3); PIN_ARR(Jw[i], 3); }
-    STAMP(2);
+    STAMP(3);
     // ---------------- A4: tool offset (vf:321-332) --------------------------------------------
     double Rt[9], pt[3], rr[3], tl[12];
     if (a.tool_stride) {
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
-    STAMP(3);
+    STAMP(4);
     {
         // Fast path, decided per wave: every prefetched slot of every lane is a decay repeller (or
         // empty) and they all share one integer decay order -- what object_feeder produces for point
@@ -555,7 +567,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int m = PRE; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
     }
     PIN_ARR(tot, 6);
-    STAMP(4);
+    STAMP(5);
     // normCart + speedScale * scalars (vf:292,346-347)
     double v[3], w[3];
     {
@@ -642,7 +654,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     }
 
     PIN_ARR(qv, NJ);
-    STAMP(5);
+    STAMP(6);
     // ---------------- A10-A13: nullspace module (nullspace:95-131,162-184) ----------------------
     double qn[NJ];
 #pragma unroll
@@ -773,8 +785,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * kc->null_gain;
     }
 
-    PIN_ARR(qn, NJ);
-    STAMP(6);
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
     double qo[NJ];
     if (a.flags & VFIK_F_MIXER) {
@@ -944,9 +954,12 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
         const Screws s = dh_factor(ch.B[i + 1]);
         worst = std::fmax(worst, dh_recompose_error(s, ch.B[i + 1]));
         const double off = phi_prev + s.theta;
+        const bool pris = ch.jtype[i] == 1;
         c.dh[i].off = off;
-        c.dh[i].coff = std::cos(off);
-        c.dh[i].soff = std::sin(off);
+        c.dh[i].crev = pris ? 0.0 : 1.0;
+        c.dh[i].cprs = pris ? std::cos(off) : 0.0;
+        c.dh[i].sprs = pris ? std::sin(off) : 0.0;
+        c.dh[i].qd = pris ? 1.0 : 0.0;
         c.dh[i].d = e_prev + s.d;
         c.dh[i].a = s.a;
         c.dh[i].ca = std::cos(s.alpha);
