@@ -75,6 +75,7 @@ struct vfik_handle {
     std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
     int fast_order = 0;
+    int plain = 0;  // chain / tool / weights allow the PLAIN kernel variant
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     Scratch sc[10];
@@ -147,6 +148,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.fast_order = h->fast_order;
     a.flags = h->params.flags;
     a.tool_stride = h->tool_per_arm ? h->Bpad : 0;
+    a.plain = (h->plain && !h->tool_per_arm) ? 1 : 0;
     a.q = io->q;
     a.goal = h->d_goal;
     a.slots = h->d_slots;
@@ -171,11 +173,13 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
 int upload_kconst(vfik_handle* h) {
     if (!h->chain_set) return VFIK_OK;
     std::vector<char> img(vfik::kconst_bytes(h->n));
-    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared);
+    int plain = 0;
+    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared, &plain);
     if (!(err < 1e-9)) return fail(VFIK_E_ARG, "chain: a fixed transform is not a rigid motion (DH recomposition error %.3e)", err);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->d_kconst, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->plain = plain;
     return VFIK_OK;
 }
 

@@ -67,6 +67,8 @@ struct KArgs {
                       // decay order (what object_feeder sends for point obstacles); -1: general path
     unsigned flags;
     int tool_stride;  // 0: one tool for the batch (KConst::tool); else per-arm tool quads ([3][Bpad])
+    int plain;        // 1: launch the PLAIN kernel variant (see vfik_kernel.hip)
+    int pad1;
     const void* q;
     const void* goal;
     const void* slots;
@@ -91,7 +93,7 @@ struct KArgs {
 // recomposition error of the DH conversion (the caller refuses a chain above 1e-9)
 size_t kconst_bytes(int nj);
 // fill a host image of KConst<nj> at dst
-double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12);
+double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12, int* plain);
 
 // Type-erased launchers (implemented in vfik_kernel.hip).  kargs points to a KArgs<nj>.
 uint32_t supported_joints_mask();

@@ -337,7 +337,10 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
 #define PIN_ARR(arr, n)
 #endif
 
-template <typename T, int NJ, bool NULLSP>
+// PLAIN = the common configuration, decided on the host: all joints revolute, last fixed transform a
+// pure z-screw already absorbed, one identity tool for the batch, unit IK weights.  The general variant
+// carries the joint-type blends, the tool product, RefPoint and the weight scaling.
+template <typename T, int NJ, bool NULLSP, bool PLAIN>
 __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     const int arm = blockIdx.x * blockDim.x + threadIdx.x;
     const long Bs = a.B;
@@ -377,30 +380,27 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int j = 0; j < rem / 4; ++j)
             __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + j * 4), (LPtr)(qrow + n16 * 1024 + j * 256), 4, 0, 0);
     }
-    {
-        const char* gg = static_cast<const char*>(a.goal) + (long)arm * QB;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
-    }
+    // The goal and slot requests are issued later, between the joints of the kinematics: a load costs
+    // the issuing wave ~50 cycles while the CU's four waves queue on the one address unit
+    // (tools/ubench_loads.hip), and spreading them out lets that queue drain under arithmetic.
     const int npre = a.slots_used < PRE ? a.slots_used : PRE;
-    {
-        const char* sg = static_cast<const char*>(a.slots) + (long)arm * QB;
-#pragma unroll
-        for (int m = 0; m < PRE; ++m) {
-            // slots past the ones in use re-request slot 0 (cache hit) and are masked below, so the
-            // number of outstanding requests is a compile-time constant for the counted waits
-            const char* sm = sg + (m < npre ? (long)m * 2 * planeB : 0);
-            stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + 2 * m * Q16);
-            stage_quad<T>(sm + planeB, region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16);
-        }
-    }
-    constexpr int N_GOAL = 4 * Q16, N_SLOT = 2 * PRE * Q16;  // requests issued after q
+    const char* const gg = static_cast<const char*>(a.goal) + (long)arm * QB;
+    const char* const sg = static_cast<const char*>(a.slots) + (long)arm * QB;
+    auto issue_slot_quad = [&](int idx) {  // idx in [0, 2 * PRE): quad idx & 1 of slot idx >> 1
+        // slots past the ones in use re-request slot 0 (cache hit) and are masked below, so the
+        // number of outstanding requests is a compile-time constant for the counted waits
+        const int m = idx >> 1;
+        const char* sm = sg + (m < npre ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+    };
+    constexpr int N_SLOT = 2 * PRE * Q16;                   // requests issued after the goal
+    constexpr int SLOTQ_PER_JOINT = (2 * PRE + NJ - 1) / NJ;  // slot quads requested after each joint
 
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
     bool big = false;
-    VFIK_WAIT_VM(N_GOAL + N_SLOT);  // constants, tool and q have landed; goal and slots still in flight
+    VFIK_WAIT_VM(0);  // constants, tool and q have landed
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
     STAMP(2);
     {
@@ -423,6 +423,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) sincos(q[i] + kl->dh[i].off, &sn[i], &cs[i]);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
     double R[9], p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -436,9 +438,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); ~33 flops, 9 constants from LDS
         Jw[i][0] = R[2]; Jw[i][1] = R[5]; Jw[i][2] = R[8];
         Jv[i][0] = p[0]; Jv[i][1] = p[1]; Jv[i][2] = p[2];
-        const double ci = __builtin_fma(kl->dh[i].crev, cs[i], kl->dh[i].cprs);
-        const double si = __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
-        const double di = __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
+        const double ci = PLAIN ? cs[i] : __builtin_fma(kl->dh[i].crev, cs[i], kl->dh[i].cprs);
+        const double si = PLAIN ? sn[i] : __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
+        const double di = PLAIN ? kl->dh[i].d : __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
         const double ai = kl->dh[i].a, ca = kl->dh[i].ca, sa = kl->dh[i].sa;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -449,8 +451,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             R[3 * r + 1] = ca * ym + sa * z;
             R[3 * r + 2] = ca * z - sa * ym;
         }
+#pragma unroll
+        for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
+            if (i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
     }
-    {   // trailing z-screw of the last fixed transform
+    if (!PLAIN) {   // trailing z-screw of the last fixed transform
         const double tc = kl->tail_c, ts = kl->tail_s, te = kl->tail_e;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -464,12 +469,16 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         {
-            const bool pris = (kc->prismatic_mask >> i) & 1u;
             const double dx = p[0] - Jv[i][0], dy = p[1] - Jv[i][1], dz = p[2] - Jv[i][2];
             const double cx = Jw[i][1] * dz - Jw[i][2] * dy, cy = Jw[i][2] * dx - Jw[i][0] * dz,
                          cz = Jw[i][0] * dy - Jw[i][1] * dx;
-            Jv[i][0] = pris ? Jw[i][0] : cx; Jv[i][1] = pris ? Jw[i][1] : cy; Jv[i][2] = pris ? Jw[i][2] : cz;
-            Jw[i][0] = pris ? 0.0 : Jw[i][0]; Jw[i][1] = pris ? 0.0 : Jw[i][1]; Jw[i][2] = pris ? 0.0 : Jw[i][2];
+            if (PLAIN) {
+                Jv[i][0] = cx; Jv[i][1] = cy; Jv[i][2] = cz;
+            } else {
+                const bool pris = (kc->prismatic_mask >> i) & 1u;
+                Jv[i][0] = pris ? Jw[i][0] : cx; Jv[i][1] = pris ? Jw[i][1] : cy; Jv[i][2] = pris ? Jw[i][2] : cz;
+                Jw[i][0] = pris ? 0.0 : Jw[i][0]; Jw[i][1] = pris ? 0.0 : Jw[i][1]; Jw[i][2] = pris ? 0.0 : Jw[i][2];
+            }
         }
     }
 
@@ -478,20 +487,28 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     for (int i = 0; i < NJ; ++i) { PIN_ARR(Jv[i], 3); PIN_ARR(Jw[i], 3); }
     STAMP(3);
     // ---------------- A4: tool offset (vf:321-332) --------------------------------------------
-    double Rt[9], pt[3], rr[3], tl[12];
-    if (a.tool_stride) {
+    double Rt[9], pt[3], rr[3];
+    if (PLAIN) {  // identity tool: the tool pose is the flange pose
 #pragma unroll
-        for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lane, tl + 4 * k);
+        for (int k = 0; k < 9; ++k) Rt[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pt[k] = p[k]; rr[k] = 0.0; }
     } else {
+        double tl[12];
+        if (a.tool_stride) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
-    }
+            for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lane, tl + 4 * k);
+        } else {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
+        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Rt[3 * r + c] = R[3 * r] * tl[c] + R[3 * r + 1] * tl[4 + c] + R[3 * r + 2] * tl[8 + c];
-        rr[r] = -(R[3 * r] * tl[3] + R[3 * r + 1] * tl[7] + R[3 * r + 2] * tl[11]);  // p_ee - p_tip
-        pt[r] = p[r] - rr[r];
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rt[3 * r + c] = R[3 * r] * tl[c] + R[3 * r + 1] * tl[4 + c] + R[3 * r + 2] * tl[8 + c];
+            rr[r] = -(R[3 * r] * tl[3] + R[3 * r + 1] * tl[7] + R[3 * r + 2] * tl[11]);  // p_ee - p_tip
+            pt[r] = p[r] - rr[r];
+        }
     }
 
     // ---------------- A5: vector field at the tool pose (vf:276-293,344-347) -------------------
@@ -582,9 +599,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 
     // ---------------- A6: Twist.RefPoint(p_ee - p_tip) (vf:456-459) ----------------------------
     double tw[6];
-    tw[0] = v[0] + (w[1] * rr[2] - w[2] * rr[1]);
-    tw[1] = v[1] + (w[2] * rr[0] - w[0] * rr[2]);
-    tw[2] = v[2] + (w[0] * rr[1] - w[1] * rr[0]);
+    tw[0] = PLAIN ? v[0] : v[0] + (w[1] * rr[2] - w[2] * rr[1]);
+    tw[1] = PLAIN ? v[1] : v[1] + (w[2] * rr[0] - w[0] * rr[2]);
+    tw[2] = PLAIN ? v[2] : v[2] + (w[0] * rr[1] - w[1] * rr[0]);
     tw[3] = w[0]; tw[4] = w[1]; tw[5] = w[2];
 
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
@@ -596,8 +613,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                S[i][r] = kc->wy[r] * Jv[i][r] * kc->wq[i];
-                S[i][3 + r] = kc->wy[3 + r] * Jw[i][r] * kc->wq[i];
+                S[i][r] = PLAIN ? Jv[i][r] : kc->wy[r] * Jv[i][r] * kc->wq[i];
+                S[i][3 + r] = PLAIN ? Jw[i][r] : kc->wy[3 + r] * Jw[i][r] * kc->wq[i];
             }
         }
         double A[6][6];
@@ -630,7 +647,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = kc->wy[i] * tw[i];
+            double t = PLAIN ? tw[i] : kc->wy[i] * tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -649,7 +666,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             double acc = 0.0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) acc += S[i][r] * y[r];
-            qv[i] = kc->wq[i] * acc;
+            qv[i] = PLAIN ? acc : kc->wq[i] * acc;
         }
     }
 
@@ -886,10 +903,14 @@ template <typename T, int NJ>
 hipError_t launch_t(const KArgs& a, int block, hipStream_t stream) {
     const dim3 grid((a.B + block - 1) / block), blk(block);
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
-    if (a.flags & VFIK_F_NULLSPACE)
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, true>), grid, blk, lds, stream, a);
-    else
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, false>), grid, blk, lds, stream, a);
+    const bool ns = a.flags & VFIK_F_NULLSPACE;
+    if (a.plain) {
+        if (ns) hipLaunchKernelGGL((cycle_kernel<T, NJ, true, true>), grid, blk, lds, stream, a);
+        else hipLaunchKernelGGL((cycle_kernel<T, NJ, false, true>), grid, blk, lds, stream, a);
+    } else {
+        if (ns) hipLaunchKernelGGL((cycle_kernel<T, NJ, true, false>), grid, blk, lds, stream, a);
+        else hipLaunchKernelGGL((cycle_kernel<T, NJ, false, false>), grid, blk, lds, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -945,7 +966,7 @@ static double dh_recompose_error(const Screws& s, const double* B) {
 }
 
 template <int NJ>
-double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, const double* tool12) {
+double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, const double* tool12, int* plain) {
     KConst<NJ>& c = *static_cast<KConst<NJ>*>(dst);
     memset(&c, 0, sizeof c);
     memcpy(c.base, ch.B[0], sizeof c.base);
@@ -987,6 +1008,13 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.null_gain = p.null_gain;
     c.lookahead = p.lookahead;
     c.max_vel = p.max_vel;
+    // PLAIN variant of the kernel: revolute joints only, no trailing screw, identity tool, unit weights
+    bool pl = c.prismatic_mask == 0 && c.tail_c == 1.0 && c.tail_s == 0.0 && c.tail_e == 0.0;
+    static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int k = 0; k < 12; ++k) pl = pl && tool12[k] == ident[k];
+    for (int i = 0; i < 6; ++i) pl = pl && p.wy[i] == 1.0;
+    for (int i = 0; i < NJ; ++i) pl = pl && p.wq[i] == 1.0;
+    *plain = pl ? 1 : 0;
     return worst;
 }
 
@@ -1018,9 +1046,9 @@ size_t kconst_bytes(int nj) {
     }
 }
 
-double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12) {
+double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12, int* plain) {
     switch (nj) {
-#define X(n) case n: return kconst_fill_t<n>(dst, chain, p, tool12);
+#define X(n) case n: return kconst_fill_t<n>(dst, chain, p, tool12, plain);
         VFIK_NJ_LIST
 #undef X
         default: return 1e300;

@@ -32,7 +32,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or os.environ.get("VFIK_HIP_LIB", _abi.HIP_LIB_PATH)
+    path = path or os.environ.get("VFIK_HIP_LIB") or _abi.HIP_LIB_PATH
     try:
         # torch ships its own libamdhip64; let it load first so that this process holds ONE HIP
         # runtime (loading /opt/rocm's copy first makes a later torch.cuda init fail)
