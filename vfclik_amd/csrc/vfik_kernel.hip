@@ -432,12 +432,15 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int c = 0; c < 3; ++c) R[3 * r + c] = kl->base[4 * r + c];
         p[r] = kl->base[4 * r + 3];
     }
-    double Jv[NJ][3], Jw[NJ][3];  // first the joint origins / axes, then the Jacobian columns
+    // Jm[i] = column i of the 6 x n Jacobian (rows 0..2 linear, 3..5 angular); during the kinematics
+    // it first holds the joint origin and axis.  The nullspace module later orthonormalises its ROWS in
+    // place (the columns are no longer needed once the IK has used them).
+    double Jm[NJ][6];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); ~33 flops, 9 constants from LDS
-        Jw[i][0] = R[2]; Jw[i][1] = R[5]; Jw[i][2] = R[8];
-        Jv[i][0] = p[0]; Jv[i][1] = p[1]; Jv[i][2] = p[2];
+        Jm[i][3] = R[2]; Jm[i][4] = R[5]; Jm[i][5] = R[8];
+        Jm[i][0] = p[0]; Jm[i][1] = p[1]; Jm[i][2] = p[2];
         const double ci = PLAIN ? cs[i] : __builtin_fma(kl->dh[i].crev, cs[i], kl->dh[i].cprs);
         const double si = PLAIN ? sn[i] : __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
         const double di = PLAIN ? kl->dh[i].d : __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
@@ -469,22 +472,22 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         {
-            const double dx = p[0] - Jv[i][0], dy = p[1] - Jv[i][1], dz = p[2] - Jv[i][2];
-            const double cx = Jw[i][1] * dz - Jw[i][2] * dy, cy = Jw[i][2] * dx - Jw[i][0] * dz,
-                         cz = Jw[i][0] * dy - Jw[i][1] * dx;
+            const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
+            const double cx = Jm[i][4] * dz - Jm[i][5] * dy, cy = Jm[i][5] * dx - Jm[i][3] * dz,
+                         cz = Jm[i][3] * dy - Jm[i][4] * dx;
             if (PLAIN) {
-                Jv[i][0] = cx; Jv[i][1] = cy; Jv[i][2] = cz;
+                Jm[i][0] = cx; Jm[i][1] = cy; Jm[i][2] = cz;
             } else {
                 const bool pris = (kc->prismatic_mask >> i) & 1u;
-                Jv[i][0] = pris ? Jw[i][0] : cx; Jv[i][1] = pris ? Jw[i][1] : cy; Jv[i][2] = pris ? Jw[i][2] : cz;
-                Jw[i][0] = pris ? 0.0 : Jw[i][0]; Jw[i][1] = pris ? 0.0 : Jw[i][1]; Jw[i][2] = pris ? 0.0 : Jw[i][2];
+                Jm[i][0] = pris ? Jm[i][3] : cx; Jm[i][1] = pris ? Jm[i][4] : cy; Jm[i][2] = pris ? Jm[i][5] : cz;
+                Jm[i][3] = pris ? 0.0 : Jm[i][3]; Jm[i][4] = pris ? 0.0 : Jm[i][4]; Jm[i][5] = pris ? 0.0 : Jm[i][5];
             }
         }
     }
 
     PIN_ARR(R, 9); PIN_ARR(p, 3);
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) { PIN_ARR(Jv[i], 3); PIN_ARR(Jw[i], 3); }
+    for (int i = 0; i < NJ; ++i) { PIN_ARR(Jm[i], 6); }
     STAMP(3);
     // ---------------- A4: tool offset (vf:321-332) --------------------------------------------
     double Rt[9], pt[3], rr[3];
@@ -532,56 +535,64 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
     STAMP(4);
     {
-        // Fast path, decided per wave: every prefetched slot of every lane is a decay repeller (or
-        // empty) and they all share one integer decay order -- what object_feeder produces for point
-        // obstacles (object_feeder:317-334).  Straight-line code, the slots interleave.
-        VFIK_WAIT_VM(0);  // all slots have landed
-        double sv[PRE][8];
-#pragma unroll
-        for (int m = 0; m < PRE; ++m) {
-            read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lane, sv[m]);
-            read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lane, sv[m] + 4);
-        }
         const T* sq = static_cast<const T*>(a.slots) + (long)arm * 4;
         const long Qp = Bp * 4;
         if (a.fast_order >= 0) {
             // Fast path, decided by the host when the field sets were packed (vfik_set_fields): every
             // used slot of every arm is a decay repeller with the same integer decay order -- what
             // object_feeder produces for point obstacles (object_feeder:317-334).  Empty slots carry
-            // force 0.  Straight-line code: the slots interleave in the schedule.
+            // force 0.  Straight-line code per chunk of PRE slots: the slots interleave in the schedule.
             const int n0 = a.fast_order;
-            double dx[PRE], dy[PRE], dz[PRE], di[PRE], rb[PRE], rp[PRE];
+            for (int c0 = 0;;) {
+                VFIK_WAIT_VM(0);  // this chunk's slots have landed
+                const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
+                double dx[PRE], dy[PRE], dz[PRE], di[PRE], rb[PRE], rp[PRE], fk[PRE];
 #pragma unroll
-            for (int m = 0; m < PRE; ++m) {
-                dx[m] = sv[m][0] - pt[0];
-                dy[m] = sv[m][1] - pt[1];
-                dz[m] = sv[m][2] - pt[2];
-                double D;
-                sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
-                di[m] = D < D_FLOOR ? 1.0 / D_FLOOR : di[m];
-                rb[m] = (sv[m][3] + sv[m][4]) * di[m];
-                rp[m] = 1.0;
-            }
-            for (int e = n0; e; ) {  // square-and-multiply, all slots in lock step
-                if (e & 1) {
-#pragma unroll
-                    for (int m = 0; m < PRE; ++m) rp[m] *= rb[m];
+                for (int m = 0; m < PRE; ++m) {
+                    double s0[4], s1[4];
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lane, s0);
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lane, s1);
+                    dx[m] = s0[0] - pt[0];
+                    dy[m] = s0[1] - pt[1];
+                    dz[m] = s0[2] - pt[2];
+                    double D;
+                    sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
+                    di[m] = fmin(di[m], 1.0 / D_FLOOR);
+                    rb[m] = (s0[3] + s1[0]) * di[m];
+                    rp[m] = 1.0;
+                    fk[m] = m < ncur ? s1[2] : 0.0;
                 }
-                e >>= 1;
-                if (e) {
+                for (int e = n0; e;) {  // square-and-multiply, all slots in lock step
+                    if (e & 1) {
 #pragma unroll
-                    for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                        for (int m = 0; m < PRE; ++m) rp[m] *= rb[m];
+                    }
+                    e >>= 1;
+                    if (e) {
+#pragma unroll
+                        for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                    }
                 }
-            }
 #pragma unroll
-            for (int m = 0; m < PRE; ++m) {
-                const double k = (m < npre ? sv[m][6] : 0.0) * fmin(rp[m], MAG_CAP) * di[m];
-                tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+                for (int m = 0; m < PRE; ++m) {
+                    const double k = fk[m] * fmin(rp[m], MAG_CAP) * di[m];
+                    tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+                }
+                c0 += PRE;
+                if (c0 >= a.slots_used) break;
+                // next chunk into the same rows: this wave's reads of them have returned
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int idx = 0; idx < 2 * PRE; ++idx) {
+                    const int m = c0 + (idx >> 1);
+                    const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+                    stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+                }
             }
         } else {
-            for (int m = 0; m < npre; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
+            VFIK_WAIT_VM(0);  // (the staged slots are not used on the general path)
+            for (int m = 0; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
         }
-        for (int m = PRE; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
     }
     PIN_ARR(tot, 6);
     STAMP(5);
@@ -607,16 +618,19 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
     double qv[NJ];
     {
-        // Jw' = Wy J Wq, kept as scaled columns
-        double S[NJ][6];
+        // Jw' = Wy J Wq, kept as scaled columns (the PLAIN variant uses J itself)
+        double Sw[PLAIN ? 1 : NJ][6];
+        if (!PLAIN) {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
+            for (int i = 0; i < NJ; ++i) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                S[i][r] = PLAIN ? Jv[i][r] : kc->wy[r] * Jv[i][r] * kc->wq[i];
-                S[i][3 + r] = PLAIN ? Jw[i][r] : kc->wy[3 + r] * Jw[i][r] * kc->wq[i];
+                for (int r = 0; r < 3; ++r) {
+                    Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
+                    Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
+                }
             }
         }
+        double (*const S)[6] = PLAIN ? Jm : Sw;
         double A[6][6];
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -677,39 +691,40 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < NJ; ++i) qn[i] = 0.0;
     if constexpr (NULLSP) {
-        // Orthonormal basis Q (rows) of the row space of J by Gram-Schmidt with re-orthogonalisation;
-        // I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
-        double Q[6][NJ];
+        // Keep the compiler from starting this module before the IK has finished with Jm: interleaved,
+        // the two keep two copies of the Jacobian alive and (n = 14) spill to scratch.  No instruction
+        // is emitted: the empty asm only ties every Jm element to the IK result.
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
+        // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
+        // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
+        // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
         int rank = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            double u[NJ];
             double n0 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                u[i] = r < 3 ? Jv[i][r < 3 ? r : 0] : Jw[i][r < 3 ? 0 : r - 3];
-                n0 += u[i] * u[i];
+            for (int i = 0; i < NJ; ++i) n0 += Jm[i][r] * Jm[i][r];
+#pragma unroll
+            for (int s = 0; s < r; ++s) {
+                double c = 0.0;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) c += Jm[i][s] * Jm[i][r];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) Jm[i][r] -= c * Jm[i][s];
             }
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-                for (int s = 0; s < r; ++s) {
-                    double c = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) c += Q[s][i] * u[i];
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) u[i] -= c * Q[s][i];
-                }
             double n1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) n1 += u[i] * u[i];
+            for (int i = 0; i < NJ; ++i) n1 += Jm[i][r] * Jm[i][r];
             const bool keep = n1 > 1e-24 * n0 && n0 > 0.0;
             double n1r, n1i;
             sqrt_rsqrt(n1, n1r, n1i);
             const double inv = keep ? n1i : 0.0;
             rank += keep ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) Q[r][i] = u[i] * inv;
+            for (int i = 0; i < NJ; ++i) Jm[i][r] *= inv;
         }
         const int nullity = NJ - rank;
         if (nullity == 1) {
@@ -720,7 +735,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             for (int i = 0; i < NJ; ++i) {
                 double d = 1.0;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) d -= Q[r][i] * Q[r][i];
+                for (int r = 0; r < 6; ++r) d -= Jm[i][r] * Jm[i][r];
                 if (d > best) { best = d; ib = i; }
             }
             double u[NJ];
@@ -732,9 +747,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 for (int r = 0; r < 6; ++r) {
                     double c = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NJ; ++i) c += Q[r][i] * u[i];
+                    for (int i = 0; i < NJ; ++i) c += Jm[i][r] * u[i];
 #pragma unroll
-                    for (int i = 0; i < NJ; ++i) u[i] -= c * Q[r][i];
+                    for (int i = 0; i < NJ; ++i) u[i] -= c * Jm[i][r];
                 }
             double nn = 0.0;
 #pragma unroll
@@ -783,9 +798,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             for (int r = 0; r < 6; ++r) {
                 double c = 0.0;
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) c += Q[r][i] * z[i];
+                for (int i = 0; i < NJ; ++i) c += Jm[i][r] * z[i];
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) z[i] -= c * Q[r][i];
+                for (int i = 0; i < NJ; ++i) z[i] -= c * Jm[i][r];
             }
 #pragma unroll
             for (int i = 0; i < NJ; ++i) qn[i] += z[i];
