@@ -71,6 +71,10 @@ int vfik_set_chain(vfik_handle* h, const vfik_chain* chain);
  * max_vel (bridge:612-623), feature flags.  Range checks of the ports are done by the host layer. */
 int vfik_set_params(vfik_handle* h, const vfik_params* p);
 
+/* Per-arm speedScale: what each arm's vf keeps after a /max_vel message (vf:197-207).  values[n_arms]
+ * for arms [first_arm, first_arm + n_arms).  vfik_set_params.speed_scale writes one value to all arms. */
+int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double* values);
+
 /* /tool (vf:321-326): 16 doubles row-major, shared by the batch (per_arm = 0) or tool16[B][16]. */
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
 
@@ -80,6 +84,11 @@ int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
  * message arrived, exactly when the reference rebuilds totalVF (vf:276-293). */
 int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field* fields,
                     int max_fields, const int32_t* counts);
+
+/* Per-arm mixer weights, w[n_arms][6]: what each arm's bridge keeps after a /bridge/weight message
+ * (command_mixer.py:48-53; handlers send [cart, null, joint, 0], handlers.py:189-204).  NULL returns every
+ * arm to the batch-wide vfik_params.mix_w. */
+int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w);
 
 /* Last command of mixer channel 2..5 (jointcmd, mechanismcmd, xtra1cmd, xtra2cmd; bridge:593-596)
  * for the whole batch: host array cmd[B][n] in the io dtype, or NULL to zero the channel, which is

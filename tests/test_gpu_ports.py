@@ -1,0 +1,159 @@
+"""End to end through the reference's interface on a GPU: handler call -> object feeder -> /param
+bottles -> batched control cycle -> /qdotOut bottles, checked against the oracle; per-arm speedScale,
+tools, mixer weights and the watchdog on an external channel; closed-loop convergence."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def net():
+    import __graft_entry__ as g
+    g.build()
+    from vfclik_amd import ports as yarp
+    yarp.Network.reset()
+    yield yarp
+    yarp.Network.reset()
+
+
+def _send(port, vals):
+    b = port.prepare()
+    b.clear()
+    for v in vals:
+        b.addDouble(float(v))
+    port.write()
+
+
+def _read(port):
+    b = port.read(False)
+    return None if b is None else np.array([b.get(i).asDouble() for i in range(b.size())])
+
+
+def _open(yarp, name, strict=False):
+    p = yarp.BufferedPortBottle()
+    p.open(name)
+    p.setStrict(strict)
+    return p
+
+
+def test_handlers_to_qdot_through_ports(net):
+    yarp = net
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots
+    from vfclik_amd.handlers import HandleArmNew
+    from vfclik_amd.object_feeder import ObjectFeeder
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    arms = ["/right", "/left", "/third"]
+    bases = ["/0/lwr" + a for a in arms]
+    clock = [100.0]
+    cc = ControlCycleBatch(chain, bases, io_dtype=np.float64, clock=lambda: clock[0])
+    feeders = [ObjectFeeder(b) for b in bases]
+    handles = [HandleArmNew(arm=a) for a in arms]
+    rng = np.random.default_rng(3)
+    q = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (3, 7))
+    goals = chain.fk(rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (3, 7))).reshape(3, 16)
+    enc = [_open(yarp, "/sim%s/encoders" % a) for a in arms]
+    outs, mixed = [], []
+    for k, b in enumerate(bases):
+        yarp.Network.connect("/sim%s/encoders" % arms[k], b + "/vectorField/qIn")
+        outs.append(_open(yarp, "/probe%d/qdot" % k))
+        mixed.append(_open(yarp, "/probe%d/mixed" % k))
+        yarp.Network.connect(b + "/vectorField/qdotOut", "/probe%d/qdot" % k)
+        yarp.Network.connect(b + "/bridge/mixed", "/probe%d/mixed" % k)
+    # user code, exactly as against the reference
+    for k, h in enumerate(handles):
+        h.go_cart([float(x) for x in goals[k]])
+    user = _open(yarp, "/user/obj")
+    yarp.Network.connect("/user/obj", bases[0] + "/ofeeder/object")
+    ob = user.prepare()
+    ob.add("set"); ob.add("ObstacleP"); ob.add(0)
+    ob.add([1.0, 0, 0, 0.3, 0, 1, 0, -0.2, 0, 0, 1, 0.6, 0, 0, 0, 1, 0.05, 5.0])
+    user.writeStrict()
+    handles[1].set_joint_control()              # arm 1: mixer weights [0, 0, 1, 0] -> only the joint channel
+    handles[2].set_tool([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.2, 0, 0, 0, 1])  # old/README.old:84
+    mv = _open(yarp, "/user/maxvel")
+    yarp.Network.connect("/user/maxvel", bases[2] + "/vectorField/max_vel")
+    _send(mv, [0.2])
+    jc = _open(yarp, "/user/jointcmd")
+    yarp.Network.connect("/user/jointcmd", bases[1] + "/bridge/jointcmd")
+    jcmd = rng.normal(size=7)
+    _send(jc, jcmd)
+    for f in feeders:
+        f.spin_once()
+    for k in range(3):
+        _send(enc[k], q[k])
+    got = cc.cycle()
+    assert got.all()
+    # oracle with the same state
+    F = np.zeros((3, 4), dtype=_abi.FIELD_DTYPE)
+    n = np.zeros(3, dtype=np.int32)
+    for k in range(3):
+        F[k, 0]["id"], F[k, 0]["type"], F[k, 0]["force"] = 1, 1, 1.0
+        F[k, 0]["p"][:16] = goals[k]
+        F[k, 0]["p"][16] = 0.1  # HandleArmNew.current_slowdown_distance (handlers.py:107)
+        n[k] = 1
+    F[0, 1]["id"], F[0, 1]["type"], F[0, 1]["force"] = 5, 2, -10.0
+    F[0, 1]["p"][:6] = [0.3, -0.2, 0.6, 0.05, 0.001, 5.0]
+    n[0] = 2
+    tools = np.tile(np.eye(4).reshape(16), (3, 1))
+    tools[2, 11] = 0.2
+    ext = np.zeros((4, 3, 7))
+    ext[0, 1] = jcmd
+    seen = {}
+    for k in range(3):
+        p = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+        p.speed_scale = 0.2 if k == 2 else 1.0
+        if k == 1:
+            for i, w in enumerate([0, 0, 1, 0, 0, 0]):
+                p.mix_w[i] = w
+        ref = oracle_c.cycle_batch(chain, p, q[k:k + 1], F[k:k + 1], n[k:k + 1], tool=tools[k], ext_cmd=ext[:, k:k + 1])
+        qd, mx = _read(outs[k]), _read(mixed[k])
+        assert np.abs(qd - ref["qdot_vf"][0]).max() < 1e-9, k
+        assert np.abs(mx - ref["qdot_out"][0]).max() < 1e-9, k
+        seen[k] = mx
+    assert np.abs(seen[1] - jcmd).max() < 1e-12  # only the joint channel passes on arm 1
+    # an arm that gets no joint angles publishes nothing (vf:312-313); the watchdog zeroes the silent
+    # joint channel after guard_time (command_mixer.py:64-66)
+    clock[0] += 2.5
+    _send(enc[1], q[1])
+    got = cc.cycle()
+    assert list(got) == [False, True, False]
+    assert _read(outs[0]) is None and _read(outs[2]) is None
+    assert np.abs(_read(mixed[1])).max() == 0.0
+    # malformed input is ignored, not fatal: wrong-size q, out-of-range speedScale, short weight bottle
+    _send(enc[0], q[0][:6])
+    _send(mv, [0.9])
+    assert not cc.cycle().any()
+    assert cc.speed[2] == 0.2
+    cc.close()
+    for f in feeders:
+        f.close()
+
+
+def test_closed_loop_reaches_the_goal(net):
+    """Kinematic simulation (the role of the external joint_sim, vfclik:99-103): q += qdot * dt.  The
+    distance to the goal must fall below the slow-down distance and keep shrinking."""
+    from vfclik_amd import _abi, engine, robots, synth
+    chain = robots.lwr()
+    B = 2048
+    w = synth.make_workload(chain, B, 0, seed=11, io_dtype=np.float64)
+    params = _abi.default_params(flags=_abi.F_MIXER | _abi.F_LIMITER, max_vel=1.5, mix_w=[1, 0, 0, 0, 0, 0])
+    eng = engine.Engine(chain, B, io_dtype=np.float64, max_slots=1, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    goal_p = w["fields"]["p"][:, 0, [3, 7, 11]]
+    q = w["q"].copy()
+    dt = 0.01
+    d0 = None
+    for it in range(600):
+        out = eng.step_host(q, want=("qdot_out", "pose"))
+        d = np.linalg.norm(out["pose"][:, [3, 7, 11]] - goal_p, axis=1)
+        if d0 is None:
+            d0 = d.copy()
+        q = np.clip(q + dt * out["qdot_out"], chain.q_lo, chain.q_hi)
+    assert np.abs(out["qdot_out"]).max() <= 1.5 + 1e-12
+    reached = d < 0.01
+    assert reached.mean() > 0.8, reached.mean()        # joint limits / singular poses stop some arms
+    assert np.median(d) < 1e-3 and np.median(d0) > 0.3
+    eng.close()

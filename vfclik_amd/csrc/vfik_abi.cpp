@@ -68,6 +68,7 @@ struct vfik_handle {
     int* d_sig = nullptr;      // [B]
     double* d_mixw = nullptr;  // [16]
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
     size_t dev_bytes = 0;
     // host bookkeeping
@@ -76,6 +77,7 @@ struct vfik_handle {
     int slots_used = 0;
     int fast_order = 0;
     int plain = 0;  // chain / tool / weights allow the PLAIN kernel variant
+    bool speed_set = false;
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     Scratch sc[10];
@@ -155,6 +157,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.tool = h->d_tool;
     a.null_control = io->null_control;
     a.ext = h->d_ext;
+    a.mixw = h->d_mixw_arm;
     a.lastvec = h->d_lastvec;
     a.sig = h->d_sig;
     a.qdot_vf = io->qdot_vf;
@@ -267,6 +270,11 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     for (double& w : p.wq) w = 1.0;
     p.mix_w[0] = p.mix_w[1] = 1.0;
     h->params = p;
+    {
+        std::vector<double> all(B, p.speed_scale);
+        if (vfik_set_speed_scale(h, 0, batch, all.data()) != VFIK_OK) return bail("speed scale");
+        h->speed_set = true;
+    }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail("sync");
     return h;
 }
@@ -275,7 +283,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -321,7 +329,14 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
         return fail(VFIK_E_ARG, "lambda, speed_scale and max_vel must be finite and >= 0");
     if ((p->flags & VFIK_F_JOINT_LIMIT_TASK) && !(p->flags & VFIK_F_NULLSPACE))
         return fail(VFIK_E_ARG, "VFIK_F_JOINT_LIMIT_TASK needs VFIK_F_NULLSPACE");
+    const bool speed_changed = !h->speed_set || p->speed_scale != h->params.speed_scale;
     h->params = *p;
+    if (speed_changed) {  // vfik_params.speed_scale is the batch-wide /max_vel value: written to every arm
+        std::vector<double> all(h->B, p->speed_scale);
+        const int rc = vfik_set_speed_scale(h, 0, h->B, all.data());
+        if (rc != VFIK_OK) return rc;
+        h->speed_set = true;
+    }
     return upload_kconst(h);
 }
 
@@ -377,7 +392,9 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, used);
     const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
     char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
-    HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
+    // plane 3 = (present, slow-down, force, speedScale): the 4th component belongs to vfik_set_speed_scale
+    HIP_TRY(hipMemcpy2DAsync(dg + 3 * pitch, qb, goal.data() + 3 * w, qb, 3 * h->esz, n_arms, hipMemcpyHostToDevice, h->stream));
     if (S > 0) {
         char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
@@ -395,6 +412,55 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         if (o >= 0) fo = o;
     }
     h->fast_order = general ? -1 : (fo < 0 ? 0 : fo);
+    return VFIK_OK;
+}
+
+int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double* values) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!values) return fail(VFIK_E_ARG, "null values");
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    for (int j = 0; j < n_arms; ++j)
+        if (!(values[j] >= 0.0) || !std::isfinite(values[j])) return fail(VFIK_E_ARG, "arm %d: speedScale must be finite and >= 0", first_arm + j);
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<char> buf((size_t)n_arms * h->esz);
+    for (int j = 0; j < n_arms; ++j) { if (h->io_dtype == 32) put<float>(buf, j, values[j]); else put<double>(buf, j, values[j]); }
+    const size_t qb = 4 * h->esz;
+    char* dst = static_cast<char*>(h->d_goal) + 3 * (size_t)h->Bpad * qb + (size_t)first_arm * qb + 3 * h->esz;
+    HIP_TRY(hipMemcpy2DAsync(dst, qb, buf.data(), h->esz, h->esz, n_arms, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    if (!w) {  // back to the batch-wide weights of vfik_params.mix_w
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_mixw_arm) { HIP_TRY(hipFree(h->d_mixw_arm)); h->d_mixw_arm = nullptr; }
+        return VFIK_OK;
+    }
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    const size_t qb = 4 * h->esz, plane = (size_t)h->Bpad * qb;
+    if (!h->d_mixw_arm) {  // first use: every arm starts from the batch-wide weights
+        if (dev_alloc(h, &h->d_mixw_arm, 2 * plane, true)) return VFIK_E_HIP;
+        std::vector<char> all(2 * plane, 0);
+        for (int b = 0; b < h->B; ++b)
+            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) {
+                const size_t idx = ((size_t)(k >> 2) * h->Bpad + b) * 4 + (k & 3);
+                if (h->io_dtype == 32) put<float>(all, idx, h->params.mix_w[k]); else put<double>(all, idx, h->params.mix_w[k]);
+            }
+        HIP_TRY(hipMemcpyAsync(h->d_mixw_arm, all.data(), all.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    std::vector<char> buf(2 * (size_t)n_arms * qb, 0);
+    for (int j = 0; j < n_arms; ++j)
+        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) {
+            const size_t idx = ((size_t)(k >> 2) * n_arms + j) * 4 + (k & 3);
+            if (h->io_dtype == 32) put<float>(buf, idx, w[j * VFIK_MIX_CHANNELS + k]); else put<double>(buf, idx, w[j * VFIK_MIX_CHANNELS + k]);
+        }
+    char* dst = static_cast<char*>(h->d_mixw_arm) + (size_t)first_arm * qb;
+    HIP_TRY(hipMemcpy2DAsync(dst, plane, buf.data(), (size_t)n_arms * qb, (size_t)n_arms * qb, 2, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
 }
 

@@ -19,11 +19,12 @@ namespace vfik {
 // 16-byte-per-lane request(s).
 //   q, qdot_*, qdist      [B][n]      batch-major (the reference's bottles: n doubles per arm)
 //   pose, pose_nt         [B][16]
-//   goal                  4 planes    frame rows 0,1,2 | (present, slow-down, force, -)
+//   goal                  4 planes    frame rows 0,1,2 | (present, slow-down, force, speedScale of the arm)
 //   slots                 2S planes   slot m = planes 2m, 2m+1 = (p0 p1 p2 p3 | p4 p5 force type);
 //                                     type -1 = continuation of the previous slot (p6..p11 / p12..p16),
 //                                     type 0 = empty
 //   tool (per-arm only)   3 planes    frame rows 0,1,2 (a shared tool lives in KConst)
+//   mixw (per-arm only)   2 planes    mixer weights w0..w3 | w4 w5 - -  (shared weights live in KConst)
 //   lastvec               [n][B] double, sig [B] int   (nullspace:91-92 for the unique basis vector)
 //   ext                   [4][B][n]   last commands of mixer channels 2..5
 // Batch-shared constants: chain geometry, limits and parameters.  They live in DEVICE memory (one
@@ -75,6 +76,7 @@ struct KArgs {
     const void* tool;
     const void* null_control;
     const void* ext;
+    const void* mixw;  // per-arm mixer weights, 2 quad planes, or NULL (KConst::mix_w for every arm)
     double* lastvec;
     int* sig;
     void* qdot_vf;

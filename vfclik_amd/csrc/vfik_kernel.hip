@@ -261,13 +261,13 @@ constexpr int PRE = 8;  // slots whose loads are issued before the kinematics (p
 // kinematics run; the arithmetic waits with counted s_waitcnt vmcnt at the three points where a
 // group of inputs is first needed.  Rows are lane-linear (lane * 16 B or lane * 4 B): conflict-free.
 //   region layout per wave, Q16 = 16-byte sub-planes per quad of T (1 for float, 2 for double):
-//     quad rows  [tool 3 | goal 4 | slots 2*PRE] x Q16 x 1 KiB, then q (16-byte and 4-byte pieces),
+//     quad rows  [tool 3 | goal 4 | slots 2*PRE | mixer weights 2] x Q16 x 1 KiB, then q (16-byte and 4-byte pieces),
 //     then the kinematics block of KConst (1-2 KiB)
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Stage {
     static constexpr int Q16 = (int)sizeof(T) / 4;           // 16-B pieces per quad
-    static constexpr int QROWS = (3 + 4 + 2 * PRE) * Q16;    // 1 KiB rows
-    static constexpr int ROW_TOOL = 0, ROW_GOAL = 3 * Q16, ROW_SLOT = 7 * Q16;
+    static constexpr int QROWS = (3 + 4 + 2 * PRE + 2) * Q16;  // 1 KiB rows
+    static constexpr int ROW_TOOL = 0, ROW_GOAL = 3 * Q16, ROW_SLOT = 7 * Q16, ROW_MIXW = (7 + 2 * PRE) * Q16;
     static constexpr int QBYTES = 4 * (int)sizeof(T);        // bytes of one quad
     // q is batch-major ([B][n]): a lane's n values are contiguous and travel as 16-byte pieces plus a
     // remainder of one to three 4-byte pieces (a 12-byte LDS-DMA did not land lane-linear on gfx950)
@@ -369,6 +369,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
         for (int k = 0; k < 3; ++k) stage_quad<T>(tg + k * planeB, region, Stage<T>::ROW_TOOL + k * Q16);
+    }
+    if (a.mixw) {  // per-arm mixer weights ([2][Bpad] quads: w0..w3 | w4 w5 - -); else KConst::mix_w
+        const char* mg = static_cast<const char*>(a.mixw) + (long)arm * QB;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) stage_quad<T>(mg + k * planeB, region, Stage<T>::ROW_MIXW + k * Q16);
     }
     {
         const char* qg = static_cast<const char*>(a.q) + (long)arm * NJ * sizeof(T);
@@ -516,11 +521,13 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 
     // ---------------- A5: vector field at the tool pose (vf:276-293,344-347) -------------------
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
+    double speed;  // this arm's speedScale (vf:134-137,197-207), 4th component of the goal block's last quad
     VFIK_WAIT_VM(N_SLOT);  // goal block has landed
     {
         double gq[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lane, gq + 4 * k);
+        speed = gq[15];
         if (gq[12] != 0.0) {  // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, -]
             double GR[9], Gp[3];
 #pragma unroll
@@ -602,8 +609,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double nt, nti, nr, nri;
         sqrt_rsqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2], nt, nti);
         sqrt_rsqrt(tot[3] * tot[3] + tot[4] * tot[4] + tot[5] * tot[5], nr, nri);
-        const double kt = nt > EPS_LEN ? kc->speed * sc[0] * nti : 0.0;
-        const double kr = nr > EPS_LEN ? kc->speed * sc[1] * nri : 0.0;
+        const double kt = nt > EPS_LEN ? speed * sc[0] * nti : 0.0;
+        const double kr = nr > EPS_LEN ? speed * sc[1] * nri : 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { v[k] = tot[k] * kt; w[k] = tot[3 + k] * kr; }
     }
@@ -820,17 +827,23 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
     double qo[NJ];
     if (a.flags & VFIK_F_MIXER) {
+        double mw[8];
+        if (a.mixw) {
+            read_quad<T>(region, Stage<T>::ROW_MIXW, lane, mw);
+            read_quad<T>(region, Stage<T>::ROW_MIXW + Q16, lane, mw + 4);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            qo[i] = mac_unfused(mac_unfused(0.0, qv[i], kc->mix_w[0]), qn[i], kc->mix_w[1]);
+            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = kc->mix_w[k];
         }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mac_unfused(0.0, qv[i], mw[0]), qn[i], mw[1]);
         if (a.ext) {
             const T* e = static_cast<const T*>(a.ext);
 #pragma unroll
             for (int ch = 0; ch < VFIK_MIX_CHANNELS - 2; ++ch)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i)
-                    qo[i] = mac_unfused(qo[i], (double)e[((long)ch * Bs + arm) * NJ + i], kc->mix_w[2 + ch]);
+                    qo[i] = mac_unfused(qo[i], (double)e[((long)ch * Bs + arm) * NJ + i], mw[2 + ch]);
         }
     } else {
 #pragma unroll

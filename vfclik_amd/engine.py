@@ -55,7 +55,9 @@ def load_library(path=None):
         "vfik_set_chain": (C.c_int, [H, C.POINTER(_abi.Chain)]),
         "vfik_set_params": (C.c_int, [H, C.POINTER(_abi.Params)]),
         "vfik_set_tool": (C.c_int, [H, C.c_void_p, C.c_int]),
+        "vfik_set_speed_scale": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "vfik_set_fields": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_set_mixer_weights": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "vfik_set_ext_cmd": (C.c_int, [H, C.c_int, C.c_void_p]),
         "vfik_reset_state": (C.c_int, [H]),
         "vfik_step": (C.c_int, [H, C.POINTER(IO)]),
@@ -152,12 +154,25 @@ class Engine:
             raise ValueError("tool must hold 16 doubles%s" % (" per arm" if per_arm else ""))
         self._chk(self.lib.vfik_set_tool(self.h, t.ctypes.data, 1 if per_arm else 0))
 
+    def set_speed_scale(self, values, first_arm=0):
+        """Per-arm speedScale (the /max_vel value each arm's vf keeps, vf:197-207)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        self._chk(self.lib.vfik_set_speed_scale(self.h, int(first_arm), len(v), v.ctypes.data))
+
     def set_fields(self, fields, counts, first_arm=0):
         f = np.ascontiguousarray(fields, dtype=_abi.FIELD_DTYPE)
         if f.ndim != 2:
             raise ValueError("fields must be (n_arms, max_fields)")
         c = np.ascontiguousarray(counts, dtype=np.int32)
         self._chk(self.lib.vfik_set_fields(self.h, int(first_arm), f.shape[0], f.ctypes.data, f.shape[1], c.ctypes.data))
+
+    def set_mixer_weights(self, weights, first_arm=0):
+        """Per-arm mixer weights (n_arms, 6); ``None`` returns to the batch-wide ``params.mix_w``."""
+        if weights is None:
+            self._chk(self.lib.vfik_set_mixer_weights(self.h, 0, 0, None))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1, _abi.MIX_CHANNELS)
+        self._chk(self.lib.vfik_set_mixer_weights(self.h, int(first_arm), w.shape[0], w.ctypes.data))
 
     def set_ext_cmd(self, channel, cmd):
         if cmd is None:

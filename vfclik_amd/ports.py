@@ -1,0 +1,271 @@
+"""In-process stand-in for the slice of the YARP Python API that vfclik uses.
+
+The reference's modules are wired by YARP ports (``yarp.BufferedPortBottle``, ``yarp.Bottle``,
+``yarp.Network``: /root/reference/scripts/vf:33,66-84, src/handlers.py:60-106).  YARP is a transport
+and out of scope; what the drop-in has to keep is the *surface* the
+reference's client code touches, so that the handler classes and the message parsers can be driven
+exactly like the originals:
+
+    import vfclik_amd.ports as yarp
+    p = yarp.BufferedPortBottle(); p.open("/0/lwr/right/vectorField/qIn")
+    b = p.prepare(); b.clear(); b.addDouble(0.1); p.write()
+
+Semantics kept: a non-strict reader sees only the newest unread message, a strict one a FIFO
+(``setStrict`` / ``writeStrict``); ``read(False)`` returns ``None`` when nothing is pending
+(the reference polls every input this way: vf:197,210,296,312); a write to an unconnected port is
+dropped; connections are by port name and may be made before either end is opened (persistent
+style, vf:121-122).
+"""
+import collections
+import threading
+import time as _time
+
+
+class Value:
+    def __init__(self, v):
+        self._v = v
+
+    # -- type tests (monitor_distance:136-137, joint_p_controller:105) --
+    def isDouble(self):
+        return isinstance(self._v, float)
+
+    def isInt(self):
+        return isinstance(self._v, int) and not isinstance(self._v, bool)
+
+    def isString(self):
+        return isinstance(self._v, str)
+
+    def isList(self):
+        return isinstance(self._v, Bottle)
+
+    # -- conversions: like YARP they never raise, a mismatch yields 0 / "" / None --
+    def asDouble(self):
+        return float(self._v) if isinstance(self._v, (int, float)) else 0.0
+
+    def asFloat64(self):
+        return self.asDouble()
+
+    def asInt(self):
+        return int(self._v) if isinstance(self._v, (int, float)) else 0
+
+    def asInt32(self):
+        return self.asInt()
+
+    def asString(self):
+        return self._v if isinstance(self._v, str) else ""
+
+    def asList(self):
+        return self._v if isinstance(self._v, Bottle) else None
+
+    def toString(self):
+        if isinstance(self._v, Bottle):
+            return "(" + self._v.toString() + ")"
+        if isinstance(self._v, str):
+            return self._v
+        return repr(self._v)
+
+
+def Value_makeString(s):  # vf:220
+    return Value(str(s))
+
+
+class Bottle:
+    def __init__(self, items=None):
+        self._items = []
+        for it in items or []:
+            self._append(it)
+
+    def _append(self, it):
+        if isinstance(it, Value):
+            self._items.append(it)
+        elif isinstance(it, (list, tuple)):
+            self._items.append(Value(Bottle(it)))
+        else:
+            self._items.append(Value(it))
+
+    def clear(self):
+        self._items = []
+
+    def addDouble(self, v):
+        self._items.append(Value(float(v)))
+
+    addFloat64 = addDouble
+
+    def addInt(self, v):
+        self._items.append(Value(int(v)))
+
+    addInt32 = addInt
+
+    def addString(self, s):
+        self._items.append(Value(str(s)))
+
+    def addList(self):
+        b = Bottle()
+        self._items.append(Value(b))
+        return b
+
+    def add(self, v):  # object_feeder:109
+        self._append(v)
+
+    def size(self):
+        return len(self._items)
+
+    def get(self, i):
+        return self._items[i] if 0 <= i < len(self._items) else Value(None)
+
+    def toString(self):
+        return " ".join(v.toString() for v in self._items)
+
+    def copy(self):
+        out = Bottle()
+        for v in self._items:
+            out._items.append(Value(v._v.copy()) if isinstance(v._v, Bottle) else Value(v._v))
+        return out
+
+    def tolist(self):
+        return [v._v.tolist() if isinstance(v._v, Bottle) else v._v for v in self._items]
+
+    def __bool__(self):  # a SWIG Bottle pointer is truthy whenever it is not NULL (vf:198 `if (botin)`)
+        return True
+
+    def __len__(self):
+        return len(self._items)
+
+
+class ContactStyle:
+    def __init__(self):
+        self.persistent = False
+
+
+class _Registry:
+    """Port names, connections and open ports of one process (the YARP name server's role)."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.ports = {}
+        self.links = collections.defaultdict(set)  # source name -> destination names
+
+    def reset(self):
+        with self.lock:
+            self.ports.clear()
+            self.links.clear()
+
+
+_REG = _Registry()
+
+
+class Network:
+    @staticmethod
+    def init():
+        pass
+
+    @staticmethod
+    def fini():
+        pass
+
+    @staticmethod
+    def connect(src, dst, style=None):
+        with _REG.lock:
+            _REG.links[src].add(dst)
+        return True
+
+    @staticmethod
+    def disconnect(src, dst):
+        with _REG.lock:
+            _REG.links[src].discard(dst)
+        return True
+
+    @staticmethod
+    def isConnected(src, dst):
+        with _REG.lock:
+            return dst in _REG.links.get(src, ()) and src in _REG.ports and dst in _REG.ports
+
+    @staticmethod
+    def exists(name):
+        with _REG.lock:
+            return name in _REG.ports
+
+    @staticmethod
+    def reset():
+        """Forget every port and connection (test isolation; not a YARP call)."""
+        _REG.reset()
+
+
+class BufferedPortBottle:
+    def __init__(self):
+        self._name = None
+        self._strict = False
+        self._queue = collections.deque()
+        self._cond = threading.Condition(_REG.lock)
+        self._out = Bottle()
+
+    # -- life cycle --
+    def open(self, name):
+        with _REG.lock:
+            self._name = name
+            _REG.ports[name] = self
+        return True
+
+    def close(self):
+        with _REG.lock:
+            if self._name and _REG.ports.get(self._name) is self:
+                del _REG.ports[self._name]
+            self._name = None
+
+    def getName(self):
+        return self._name
+
+    def setStrict(self, strict=True):
+        self._strict = bool(strict)
+
+    # -- writing --
+    def prepare(self):
+        self._out = Bottle()
+        return self._out
+
+    def write(self, strict=False):
+        msg = self._out
+        with _REG.lock:
+            for dst in list(_REG.links.get(self._name, ())):
+                port = _REG.ports.get(dst)
+                if port is not None:
+                    port._deliver(msg.copy(), strict)
+        self._out = Bottle()
+
+    def writeStrict(self):
+        self.write(True)
+
+    def _deliver(self, bottle, strict):
+        with self._cond:
+            if not (self._strict or strict):
+                self._queue.clear()  # only the newest message survives on a non-strict reader
+            self._queue.append(bottle)
+            self._cond.notify_all()
+
+    # -- reading --
+    def read(self, shouldWait=True):
+        with self._cond:
+            if shouldWait:
+                while not self._queue:
+                    self._cond.wait(0.05)
+            if not self._queue:
+                return None
+            return self._queue.popleft()
+
+    def getPendingReads(self):
+        with self._cond:
+            return len(self._queue)
+
+
+class Time:
+    @staticmethod
+    def delay(s):
+        _time.sleep(s)
+
+    @staticmethod
+    def now():
+        return _time.time()
+
+
+def Time_delay(s):  # nullspace:187
+    _time.sleep(s)

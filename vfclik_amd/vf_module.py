@@ -1,0 +1,234 @@
+"""The per-cycle control modules of vfclik for B arms behind the reference's port interface.
+
+One :class:`ControlCycleBatch` stands where the reference runs, PER ARM, a ``vf`` process
+(/root/reference/scripts/vf), a ``nullspace`` process (scripts/nullspace), a ``debug_jointlimits``
+process and the ``CommandMixer`` inside ``bridge`` (scripts/bridge:593-596,626).  It opens the same
+ports under each arm's base name (``<namespace><robotarm_portbasename>``, e.g. ``/0/lwr/right``):
+
+    <base>/vectorField/{qIn,qdotOut,param,tool,weight,max_vel,pose,pose_no_tool,pose_in,vector_out}  (vf:69-84)
+    <base>/nullspace/{qin,control,qdotout}                                                           (nullspace:142-144)
+    <base>/debug/{qin,qdist}                                                                         (debug_jointlimits:46-47)
+    <base>/bridge/{encoders,weight,current_weights,jointcmd,mechanismcmd,xtra1cmd,xtra2cmd,mixed}    (bridge:564-573)
+
+:meth:`cycle` does what one iteration of each of those loops does -- poll every input non-blocking,
+ignore malformed bottles with a warning, keep sticky state -- and then runs ONE ``vfik_step`` for
+the whole batch.  Arms that received no joint angles this cycle publish nothing (vf:312-313).
+
+Port I/O is per arm and in Python, so this layer is for drop-in use and tests; a caller that already
+holds batched arrays uses :meth:`step_arrays` (or ``Engine`` directly) and never touches a bottle.
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import _abi
+from . import ports as yarp
+from .engine import Engine
+from .fields import FieldSets
+
+log = logging.getLogger("vfclik_amd.vf")
+
+CONFIG_MAX_VEL = 0.41  # vf:134
+MIX_PORTS = ("vectorfieldcmd", "nullcmd", "jointcmd", "mechanismcmd", "xtra1cmd", "xtra2cmd")  # bridge:593-596
+
+
+def _bottle_doubles(b):
+    return [b.get(i).asDouble() for i in range(b.size())]
+
+
+def _send(port, values, ints=()):
+    b = port.prepare()
+    b.clear()
+    for v in values:
+        b.addDouble(float(v))
+    for v in ints:
+        b.addInt(int(v))
+    port.write()
+
+
+class ControlCycleBatch:
+    def __init__(self, chain, arm_bases, io_dtype=np.float64, max_fields=16, device=0, nullspace=True,
+                 mixer=True, guard_time=2.0, params=None, open_ports=True, clock=time.time):
+        self.chain = chain
+        self.bases = list(arm_bases)
+        self.B = len(self.bases)
+        self.n = chain.n
+        flags = (_abi.F_NULLSPACE if nullspace else 0) | (_abi.F_MIXER if mixer else 0)
+        self.params = params if params is not None else _abi.default_params(flags=flags)
+        self.engine = Engine(chain, self.B, io_dtype=io_dtype, max_slots=3 * max_fields, device=device, params=self.params)
+        self.fields = FieldSets(self.B, max_fields)
+        self.clock = clock
+        self.guard_time = guard_time
+        self.speed = np.full(self.B, float(self.params.speed_scale))
+        self.tools = np.tile(np.eye(4).reshape(16), (self.B, 1))  # vf:154
+        self._tools_dirty = False
+        self.q = np.zeros((self.B, self.n))
+        self.control = np.zeros((self.B, _abi.NULL_CONTROLS))  # nullspace:137
+        self.mix_w = np.tile(np.array(list(self.params.mix_w)), (self.B, 1))  # bridge:596
+        self._mix_dirty = False
+        self.ext = np.zeros((4, self.B, self.n))
+        self.ext_time = np.full((4, self.B), self.clock())
+        self._ext_dirty = [False] * 4
+        self.report_counter = 0  # vf:185,432-435
+        self.last = {}
+        self.ports = []
+        if open_ports:
+            self._open_ports()
+
+    # -- ports ------------------------------------------------------------------------------------
+    def _open_ports(self):
+        def mk(name, strict=False):
+            p = yarp.BufferedPortBottle()
+            p.open(name)
+            p.setStrict(strict)
+            return p
+
+        for base in self.bases:
+            vf, ns, dbg, br = base + "/vectorField", base + "/nullspace", base + "/debug", base + "/bridge"
+            d = {
+                "qIn": mk(vf + "/qIn"), "qdotOut": mk(vf + "/qdotOut"), "param": mk(vf + "/param", True),
+                "tool": mk(vf + "/tool", True), "weight": mk(vf + "/weight", True), "max_vel": mk(vf + "/max_vel", True),
+                "pose": mk(vf + "/pose"), "pose_no_tool": mk(vf + "/pose_no_tool"), "pose_in": mk(vf + "/pose_in"),
+                "vector_out": mk(vf + "/vector_out"),
+                "ns_qin": mk(ns + "/qin"), "ns_control": mk(ns + "/control"), "ns_qdotout": mk(ns + "/qdotout"),
+                "dbg_qin": mk(dbg + "/qin"), "qdist": mk(dbg + "/qdist"),
+                "encoders": mk(br + "/encoders"), "br_weight": mk(br + "/weight", True),
+                "current_weights": mk(br + "/current_weights"), "mixed": mk(br + "/mixed"),
+            }
+            for k in MIX_PORTS[2:]:
+                d[k] = mk(br + "/" + k)
+            self.ports.append(d)
+            # the wiring the reference modules make themselves (vf:129-131, bridge:578-582, nullspace:153-154)
+            yarp.Network.connect(br + "/encoders", vf + "/qIn")
+            yarp.Network.connect(br + "/encoders", ns + "/qin")
+            yarp.Network.connect(br + "/encoders", dbg + "/qin")
+
+    def close(self):
+        for d in self.ports:
+            for p in d.values():
+                p.close()
+        self.ports = []
+        self.engine.close()
+
+    # -- the polling half of the reference loops ----------------------------------------------------
+    def _poll(self):
+        got_q = np.zeros(self.B, dtype=bool)
+        now = self.clock()
+        for a, d in enumerate(self.ports):
+            for b in self._drain(d["max_vel"]):  # vf:197-207
+                v = b.get(0).asDouble()
+                if 0.0 <= v <= CONFIG_MAX_VEL:
+                    self.speed[a] = v
+                    self.engine.set_speed_scale([v], first_arm=a)
+                else:
+                    log.warning("arm %d: speedScale not between 0.0 and config_max_vel, ignoring", a)
+            while True:  # strict port: every /param message counts (vf:210-275)
+                b = d["param"].read(False)
+                if b is None:
+                    break
+                self.fields.handle_param(a, b)
+            for b in self._drain(d["weight"]):  # vf:296-309
+                if b.size() >= 1:
+                    self._handle_weight(a, b)
+            for b in self._drain(d["tool"]):  # vf:321-326: sticky, 16 values or ignored
+                if b.size() == 16:
+                    self.tools[a] = _bottle_doubles(b)
+                    self._tools_dirty = True
+            b = d["ns_control"].read(False)  # nullspace:169-173
+            if b is not None:
+                vals = _bottle_doubles(b)[: _abi.NULL_CONTROLS]
+                self.control[a, :] = 0.0
+                self.control[a, : len(vals)] = vals
+            for b in self._drain(d["br_weight"]):  # command_mixer.py:48-53
+                for i in range(min(b.size(), _abi.MIX_CHANNELS)):
+                    self.mix_w[a, i] = b.get(i).asDouble()
+                self._mix_dirty = True
+            for ch, name in enumerate(MIX_PORTS[2:]):  # command_mixer.py:56-69
+                b = d[name].read(False)
+                if b and b.size() == self.n:
+                    self.ext[ch, a] = _bottle_doubles(b)
+                    self.ext_time[ch, a] = now
+                    self._ext_dirty[ch] = True
+                elif now - self.ext_time[ch, a] > self.guard_time:
+                    if self.ext[ch, a].any():
+                        self.ext[ch, a] = 0.0
+                        self._ext_dirty[ch] = True
+                elif b:
+                    log.warning("arm %d: wrong length for data bottle on %s", a, name)
+            b = d["qIn"].read(False)  # vf:312-313
+            d["ns_qin"].read(False)
+            d["dbg_qin"].read(False)
+            if b and b.size() == self.n:
+                self.q[a] = _bottle_doubles(b)
+                got_q[a] = True
+        return got_q
+
+    @staticmethod
+    def _drain(port):
+        """All pending bottles of a strict (configuration) port, oldest first.  The reference reads one
+        per loop iteration at ~1 kHz and so reaches the same final state a few iterations later."""
+        out = []
+        while True:
+            b = port.read(False)
+            if b is None:
+                return out
+            out.append(b)
+
+    def _handle_weight(self, arm, b):
+        """'t' + 6 or 'j' + n doubles (vf:164-179,296-309).  The IK weights are one set per handle:
+        a message on any arm's port sets them for the batch (arms that need their own weights belong
+        in their own ControlCycleBatch)."""
+        kind = b.get(0).asString()
+        n_vars = 6 if kind == "t" else self.n if kind == "j" else None
+        if n_vars is None:
+            return
+        if b.size() != n_vars + 1:
+            log.warning("arm %d: wrong size of %s weights, ignored", arm, kind)
+            return
+        w = [b.get(i + 1).asDouble() for i in range(n_vars)]
+        self.engine.set_params(**({"wy": w} if kind == "t" else {"wq": w}))
+
+    def _push_state(self):
+        self.fields.flush(self.engine)
+        if self._tools_dirty:
+            self.engine.set_tool(self.tools, per_arm=True)
+            self._tools_dirty = False
+        if self._mix_dirty:
+            self.engine.set_mixer_weights(self.mix_w)
+            self._mix_dirty = False
+        for ch in range(4):
+            if self._ext_dirty[ch]:
+                self.engine.set_ext_cmd(2 + ch, self.ext[ch])
+                self._ext_dirty[ch] = False
+
+    # -- one control cycle ---------------------------------------------------------------------------
+    def cycle(self):
+        got_q = self._poll()
+        self._push_state()
+        if not got_q.any():
+            return got_q
+        out = self.engine.step_host(self.q, null_control=self.control,
+                                    want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status"))
+        self.last = out
+        self.report_counter += 1
+        report = self.report_counter > 20  # vf:432-435
+        if report:
+            self.report_counter = 0
+        for a in np.nonzero(got_q)[0]:
+            d = self.ports[a]
+            _send(d["pose"], out["pose"][a])                 # vf:341
+            _send(d["pose_no_tool"], out["pose_nt"][a])      # vf:342
+            _send(d["qdotOut"], out["qdot_vf"][a])           # vf:462-466
+            _send(d["ns_qdotout"], out["qdot_null"][a])      # nullspace:180-184
+            _send(d["qdist"], 100.0 * out["qdist"][a])       # debug_jointlimits:68-73
+            _send(d["mixed"], out["qdot_out"][a])            # what bridge.set_vel receives (bridge:626)
+            _send(d["current_weights"], self.mix_w[a])       # bridge:627
+            if report:
+                _send(d["vector_out"], out["v6"][a])         # vf:437-442
+        return got_q
+
+    def step_arrays(self, q, null_control=None, want=("qdot_out",)):
+        """Array path: one cycle for the whole batch without any bottle."""
+        self._push_state()
+        return self.engine.step_host(q, null_control=null_control, want=want)
