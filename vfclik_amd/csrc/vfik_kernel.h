@@ -69,7 +69,7 @@ struct KArgs {
     unsigned flags;
     int tool_stride;  // 0: one tool for the batch (KConst::tool); else per-arm tool quads ([3][Bpad])
     int plain;        // 1: launch the PLAIN kernel variant (see vfik_kernel.hip)
-    int pad1;
+    int block;        // threads per block of the launch (read from here: blockDim.x costs its own scalar load)
     const void* q;
     const void* goal;
     const void* slots;

@@ -97,6 +97,79 @@ __device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
     c = ((n + 1) & 2) ? -cv : cv;
 }
 
+// The same for N independent arguments, written operation by operation across the N (structure-of-
+// arrays order): a lone wave issues a dependent float64 op every ~8 cycles but independent ones every
+// ~5, and the scheduler mostly keeps source order, so the source is laid out interleaved.
+template <int N>
+__device__ __forceinline__ void sincos_fast_n(const double* x, double* s, double* c) {
+    double k[N], r[N], z[N], ps[N], pc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = __builtin_rint(x[i] * 6.36619772367581382433e-01);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-k[i], 1.57079632673412561417e+00, x[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-k[i], 6.07710050630396597660e-11, r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-k[i], 2.02226624879595063154e-21, r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+        pc[i] = __builtin_fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], ps[i], 2.75573137070700676789e-06);
+        pc[i] = __builtin_fma(z[i], pc[i], -2.75573143513906633035e-07);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], ps[i], -1.98412698298579493134e-04);
+        pc[i] = __builtin_fma(z[i], pc[i], 2.48015872894767294178e-05);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], ps[i], 8.33333333332248946124e-03);
+        pc[i] = __builtin_fma(z[i], pc[i], -1.38888888888741095749e-03);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], ps[i], -1.66666666666666324348e-01);
+        pc[i] = __builtin_fma(z[i], pc[i], 4.16666666666666019037e-02);
+    }
+    double zr[N], zz[N], hh[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { zr[i] = z[i] * r[i]; zz[i] = z[i] * z[i]; hh[i] = __builtin_fma(z[i], -0.5, 1.0); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { ps[i] = __builtin_fma(zr[i], ps[i], r[i]); pc[i] = __builtin_fma(zz[i], pc[i], hh[i]); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int n = (int)k[i];
+        const double sv = (n & 1) ? pc[i] : ps[i], cv = (n & 1) ? ps[i] : pc[i];
+        s[i] = (n & 2) ? -sv : sv;
+        c[i] = ((n + 1) & 2) ? -cv : cv;
+    }
+}
+
+// N independent 1/sqrt(x), operation by operation (x = 0 gives a large finite value)
+template <int N>
+__device__ __forceinline__ void rsqrt_n(const double* x, double* inv) {
+    double y[N], g[N], h[N], r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = __builtin_amdgcn_rsq(fmax(x[i], 1e-300));
+#pragma unroll
+    for (int i = 0; i < N; ++i) { g[i] = x[i] * y[i]; h[i] = 0.5 * y[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-g[i], h[i], 0.5);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { g[i] = __builtin_fma(g[i], r[i], g[i]); h[i] = __builtin_fma(h[i], r[i], h[i]); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-g[i], h[i], 0.5);
+#pragma unroll
+    for (int i = 0; i < N; ++i) inv[i] = 2.0 * __builtin_fma(h[i], r[i], h[i]);
+}
+
 // x^n, n a wave-uniform small non-negative integer: square-and-multiply with scalar control flow
 __device__ __forceinline__ double powi_uniform(double x, int n) {
     double r = 1.0, b = x;
@@ -342,7 +415,11 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
 // carries the joint-type blends, the tool product, RefPoint and the weight scaling.
 template <typename T, int NJ, bool NULLSP, bool PLAIN>
 __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
-    const int arm = blockIdx.x * blockDim.x + threadIdx.x;
+    // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
+    // compiler loads them one by one, each time waiting out a full scalar-load latency.
+    asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots),
+                 "s"(a.tool), "s"(a.mixw), "s"(a.kc));
+    const int arm = blockIdx.x * a.block + threadIdx.x;
     const long Bs = a.B;
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
@@ -422,8 +499,12 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             big = big || !(fabs(q[i]) <= SINCOS_FAST_MAX);
         }
     }
+    {
+        double ang[NJ];
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) sincos_fast(q[i] + kl->dh[i].off, sn[i], cs[i]);  // independent: interleaved by the scheduler
+        for (int i = 0; i < NJ; ++i) ang[i] = q[i] + kl->dh[i].off;
+        sincos_fast_n<NJ>(ang, sn, cs);
+    }
     if (__any(big)) {  // out-of-range or NaN angle somewhere in the wave: full-range sincos
 #pragma unroll
         for (int i = 0; i < NJ; ++i) sincos(q[i] + kl->dh[i].off, &sn[i], &cs[i]);
@@ -450,15 +531,20 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         const double si = PLAIN ? sn[i] : __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
         const double di = PLAIN ? kl->dh[i].d : __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
         const double ai = kl->dh[i].a, ca = kl->dh[i].ca, sa = kl->dh[i].sa;
+        double xn[3], ym[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double x = R[3 * r], y = R[3 * r + 1], z = R[3 * r + 2];
-            const double xn = ci * x + si * y, ym = ci * y - si * x;
-            p[r] += di * z + ai * xn;
-            R[3 * r] = xn;
-            R[3 * r + 1] = ca * ym + sa * z;
-            R[3 * r + 2] = ca * z - sa * ym;
-        }
+        for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { xn[r] = __builtin_fma(ci, R[3 * r], xn[r]); ym[r] = __builtin_fma(ci, R[3 * r + 1], -ym[r]); }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = __builtin_fma(di, R[3 * r + 2], p[r]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { p[r] = __builtin_fma(ai, xn[r], p[r]); R[3 * r] = xn[r]; }
+        double t1[3], t2[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { t1[r] = sa * R[3 * r + 2]; t2[r] = sa * ym[r]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
             if (i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
@@ -642,28 +728,31 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                double acc = (r == c) ? kc->lambda2 : 0.0;
+            for (int c = 0; c <= r; ++c) A[r][c] = (r == c) ? kc->lambda2 : 0.0;
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) acc += S[i][r] * S[i][c];
-                A[r][c] = acc;
-            }
+        for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
         // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
         double dinv[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
+            double v[6];  // v_k = L_jk d_k
+#pragma unroll
+            for (int k = 0; k < j; ++k) v[k] = A[j][k] * A[k][k];
             double dj = A[j][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) dj -= A[j][k] * A[j][k] * A[k][k];
+            for (int k = 0; k < j; ++k) dj = __builtin_fma(-A[j][k], v[k], dj);
             A[j][j] = dj;
             dinv[j] = rcp_nr(dj);
 #pragma unroll
-            for (int i = j + 1; i < 6; ++i) {
-                double t = A[i][j];
+            for (int k = 0; k < j; ++k)  // rows below j, one k at a time: the rows are independent chains
 #pragma unroll
-                for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k] * A[k][k];
-                A[i][j] = t * dinv[j];
-            }
+                for (int i = j + 1; i < 6; ++i) A[i][j] = __builtin_fma(-A[i][k], v[k], A[i][j]);
+#pragma unroll
+            for (int i = j + 1; i < 6; ++i) A[i][j] *= dinv[j];
         }
         double y[6];
 #pragma unroll
@@ -683,11 +772,14 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             y[i] = t;
         }
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            double acc = 0.0;
+        for (int i = 0; i < NJ; ++i) qv[i] = S[i][0] * y[0];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) acc += S[i][r] * y[r];
-            qv[i] = PLAIN ? acc : kc->wq[i] * acc;
+        for (int r = 1; r < 6; ++r)
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) qv[i] = __builtin_fma(S[i][r], y[r], qv[i]);
+        if (!PLAIN) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) qv[i] *= kc->wq[i];
         }
     }
 
@@ -928,7 +1020,9 @@ __global__ void __launch_bounds__(256) mix_kernel(const T* cmds, const double* w
 }
 
 template <typename T, int NJ>
-hipError_t launch_t(const KArgs& a, int block, hipStream_t stream) {
+hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream) {
+    KArgs a = a0;
+    a.block = block;
     const dim3 grid((a.B + block - 1) / block), blk(block);
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     const bool ns = a.flags & VFIK_F_NULLSPACE;
