@@ -28,16 +28,20 @@ for _ in range(5):
     eng.step(ioo)
 eng.sync()
 nw = (B + 63) // 64
-st = np.zeros((nw, 8), dtype=np.uint64)
+st = np.zeros((nw, 10), dtype=np.uint64)
 eng.lib.vfik_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert eng.lib.vfik_debug_read_stamps(eng.h, st.ctypes.data) == 0
-d = np.diff(st.astype(np.int64), axis=1)
+d = np.diff(st[:, :8].astype(np.int64), axis=1)
 names = ["issue loads", "wait for q", "sincos+FK+J", "tool+goal attractor", "slots", "normCart+RefPt+IK", "nullspace+mixer+stores"]
 print("workload", wl, "waves", nw)
 for i in range(7):
     print("  %-22s median %7.0f  p10 %7.0f  p90 %7.0f ticks" % (names[i], np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
 tot = (st[:, 7] - st[:, 0]).astype(np.int64)
 print("  %-16s median %7.0f  p10 %7.0f  p90 %7.0f ticks" % ("whole wave", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
+rt = (st[:, 9] - st[:, 8]).astype(np.int64)  # s_memrealtime ticks (100 MHz) over the same interval
+ok = rt > 0
+print("  shader clock from s_memtime / s_memrealtime: %.3f GHz (median over waves)" % np.median(tot[ok] / rt[ok] * 0.1))
+print("  kernel span by s_memrealtime: first wave start -> last wave end %.2f us" % ((int(st[:, 9].max()) - int(st[:, 8].min())) / 100.0))
 span = int(st[:, 7].max() - st[:, 0].min())
 print("  first start -> last end: %d ticks; wave start spread %d ticks" % (span, int(st[:, 0].max() - st[:, 0].min())))
 ms = eng.time_steps(ioo, 5, 50)

@@ -242,7 +242,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     h->esz = io_dtype == 32 ? 4 : 8;
     if (const char* e = std::getenv("VFIK_BLOCK")) {
         int b = std::atoi(e);
-        if (b == 64 || b == 128 || b == 192) h->block = b;  // LDS staging: <= 3 waves (51 KB each for float64 I/O)
+        if (b == 64 || b == 128 || b == 192 || b == 256) h->block = b;  // tuning knob; LDS per block = waves x 27-56 KB
     }
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
@@ -259,7 +259,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     h->slots_per_arm.assign(B, 0);
     h->arm_order.assign(B, -1);
 #ifdef VFIK_STAMPS
-    if (dev_alloc(h, (void**)&h->d_stamps, ((B + 63) / 64) * 8 * sizeof(unsigned long long), true)) return bail("alloc stamps");
+    if (dev_alloc(h, (void**)&h->d_stamps, ((B + 63) / 64) * 10 * sizeof(unsigned long long), true)) return bail("alloc stamps");
 #endif
     // defaults: identity tool (vf:154), sig = 1 (nullspace:91), reference default parameters
     if (vfik_reset_state(h) != VFIK_OK) return bail("reset_state");
@@ -622,7 +622,7 @@ int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, fl
 int vfik_debug_read_stamps(vfik_handle* h, unsigned long long* dst) {
     if (check_handle(h)) return VFIK_E_ARG;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(dst, h->d_stamps, (size_t)((h->B + 63) / 64) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, h->d_stamps, (size_t)((h->B + 63) / 64) * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VFIK_OK;
 }
 #endif

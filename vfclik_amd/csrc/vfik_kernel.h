@@ -54,6 +54,7 @@ struct KConst {
     double mix_w[VFIK_MIX_CHANNELS];
     double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
     double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
+    double cos_slow;  // cos(rot_slow): rotation angles with a smaller cosine need no atan2 (scalar = 1)
     unsigned prismatic_mask;
     unsigned pad0;
     static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;

@@ -69,10 +69,9 @@ __device__ __forceinline__ double mac_unfused(double acc, double x, double w) {
     return acc + prod;
 }
 
-// sin and cos for |x| <= SINCOS_FAST_MAX: Cody-Waite reduction by pi/2 in three parts, then the
-// classic minimax kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos),
-// < 1 ulp.  Joint angles live inside their limits (a few radians); anything larger takes sincos().
-constexpr double SINCOS_FAST_MAX = 1.0e5;
+// sin and cos: Cody-Waite reduction by pi/2 in three parts, then the classic minimax kernels on
+// [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos), < 1 ulp for |x| up to ~1e5 rad.
+// Joint angles live inside their limits (a few radians).
 __device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
     const double k = __builtin_rint(x * 6.36619772367581382433e-01);
     double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
@@ -200,8 +199,13 @@ __device__ __forceinline__ double pow_order(double x, double order) {
     return isint ? powi_uniform(x, n) : pow(x, order);
 }
 
-// Rotation vector (base frame) taking R to G: log(G R^T) = KDL diff(R, G).rot.  Returns |r|.
-__device__ double rot_log(const double* R, const double* G, double* r) {
+// Unit rotation axis (base frame) and angle of the rotation taking R to G, i.e. of log(G R^T) =
+// KDL diff(R, G).rot.  Branch-free main line; the half-turn neighbourhood (sin(theta) < 1e-4, cos < 0),
+// where the antisymmetric part vanishes, is fixed up from the symmetric part under a wave-uniform
+// test.  The angle itself is only needed below the slow-down angle: `need_theta` (wave-uniform) says
+// whether any lane can be that close; otherwise theta is reported as pi (any value >= rot_slow does).
+__device__ __forceinline__ void rot_axis_angle(const double* R, const double* G, double cos_slow, double* axis, double& theta,
+                                               bool& has_axis) {
     double E[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -211,8 +215,12 @@ __device__ double rot_log(const double* R, const double* G, double* r) {
     const double c = 0.5 * (E[0] + E[4] + E[8] - 1.0);
     double s, sinv;
     sqrt_rsqrt(a0 * a0 + a1 * a1 + a2 * a2, s, sinv);
-    const double th = atan2(s, c);
-    if (s < 1e-4 && c < 0.0) {
+    axis[0] = a0 * sinv; axis[1] = a1 * sinv; axis[2] = a2 * sinv;
+    has_axis = s >= EPS_LEN;
+    theta = 3.14159265358979323846;
+    if (__any(c > cos_slow)) theta = atan2(s, c);  // some lane is within the slow-down angle
+    const bool half_turn = s < 1e-4 && c < 0.0;
+    if (__any(half_turn)) {
         // theta near pi (rare): axis from the symmetric part  c I + (1-c) a a^T
         const double omc = 1.0 - c;
         double x, y, z;
@@ -230,34 +238,34 @@ __device__ double rot_log(const double* R, const double* G, double* r) {
             y = 0.5 * (E[5] + E[7]) / (omc * z);
         }
         if (x * a0 + y * a1 + z * a2 < 0.0) { x = -x; y = -y; z = -z; }
-        const double k = th / sqrt(x * x + y * y + z * z);
-        r[0] = x * k; r[1] = y * k; r[2] = z * k;
-        return th;
+        const double k = 1.0 / sqrt(x * x + y * y + z * z);
+        if (half_turn) {
+            axis[0] = x * k; axis[1] = y * k; axis[2] = z * k;
+            has_axis = true;
+            theta = atan2(s, c);
+        }
     }
-    if (s < EPS_LEN) { r[0] = r[1] = r[2] = 0.0; return th; }
-    const double k = th * sinv;
-    r[0] = a0 * k; r[1] = a1 * k; r[2] = a2 * k;
-    return th;
 }
 
-// type 1, point attractor: G = goal rotation (9) + position (3); adds force*vector to tot, scales sc
+// type 1, point attractor: G = goal rotation (9) + position (3); adds force*vector to tot, scales sc.
+// `on` masks the whole contribution (goal block absent): selects instead of a branch.
 __device__ __forceinline__ void attractor(const double* R, const double* p, const double* GR, const double* Gp,
-                                          double slow, double force, double rot_slow, double* tot, double* sc) {
+                                          double slow, double force, double rot_slow, double cos_slow, bool on,
+                                          double* tot, double* sc) {
     const double dx = Gp[0] - p[0], dy = Gp[1] - p[1], dz = Gp[2] - p[2];
     double D, Dinv;
     sqrt_rsqrt(dx * dx + dy * dy + dz * dz, D, Dinv);
-    if (D > EPS_LEN) {
-        const double k = force * Dinv;
-        tot[0] += dx * k; tot[1] += dy * k; tot[2] += dz * k;
-    }
-    double r[3];
-    const double th = rot_log(R, GR, r);
-    if (th > EPS_LEN) {
-        const double k = force * rcp_nr(th);
-        tot[3] += r[0] * k; tot[4] += r[1] * k; tot[5] += r[2] * k;
-    }
-    sc[0] *= slow > 0.0 ? fmin(1.0, D * rcp_nr(slow)) : 1.0;
-    sc[1] *= rot_slow > 0.0 ? fmin(1.0, th * rcp_nr(rot_slow)) : 1.0;
+    const double kt = (on && D > EPS_LEN) ? force * Dinv : 0.0;
+    tot[0] += dx * kt; tot[1] += dy * kt; tot[2] += dz * kt;
+    double ax[3], th;
+    bool has_axis;
+    rot_axis_angle(R, GR, cos_slow, ax, th, has_axis);
+    const bool rot_on = on && has_axis && th > EPS_LEN;  // selects, not a multiply by 0: an absent goal's axis may be NaN
+    tot[3] += rot_on ? ax[0] * force : 0.0; tot[4] += rot_on ? ax[1] * force : 0.0; tot[5] += rot_on ? ax[2] * force : 0.0;
+    const double s0 = slow > 0.0 ? fmin(1.0, D * rcp_nr(slow)) : 1.0;
+    const double s1 = rot_slow > 0.0 ? fmin(1.0, th * rcp_nr(rot_slow)) : 1.0;
+    sc[0] *= on ? s0 : 1.0;
+    sc[1] *= on ? s1 : 1.0;
 }
 
 // Element e (0..7) of slot m of this lane's arm in the quad-plane layout (vfik_kernel.h): plane
@@ -271,7 +279,8 @@ __device__ __forceinline__ double slot_elem(const T* sq, long Q, int m, int e) {
 // One field slot of any type, read from memory (the general path: mixed primitive types in a wave,
 // fractional decay orders, more slots than the prefetch window).
 template <typename T>
-__device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const double* pt, double rot_slow, double* tot, double* sc) {
+__device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const double* pt, double rot_slow, double cos_slow,
+                          double* tot, double* sc) {
     const int type = (int)slot_elem(sq, Q, m, 7);
     if (type <= 0) return;
     const double p0 = slot_elem(sq, Q, m, 0), p1 = slot_elem(sq, Q, m, 1), p2 = slot_elem(sq, Q, m, 2),
@@ -322,7 +331,7 @@ __device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const do
         GR[5] = slot_elem(sq, Q, m + 1, 0); Gp[1] = slot_elem(sq, Q, m + 1, 1);
         GR[6] = slot_elem(sq, Q, m + 1, 2); GR[7] = slot_elem(sq, Q, m + 1, 3); GR[8] = slot_elem(sq, Q, m + 1, 4);
         Gp[2] = slot_elem(sq, Q, m + 1, 5);
-        attractor(Rt, pt, GR, Gp, slot_elem(sq, Q, m + 2, 4), force, rot_slow, tot, sc);
+        attractor(Rt, pt, GR, Gp, slot_elem(sq, Q, m + 2, 4), force, rot_slow, cos_slow, true, tot, sc);
     }
 }
 
@@ -397,7 +406,10 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
         unsigned long long t_;                                                                     \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if ((threadIdx.x & 63) == 0) a.stamps[(long)(arm >> 6) * 8 + (i)] = t_;                    \
+        if ((threadIdx.x & 63) == 0) {                                                            \
+            a.stamps[(long)(arm >> 6) * 10 + (i)] = t_;                                            \
+            if ((i) == 0 || (i) == 7) a.stamps[(long)(arm >> 6) * 10 + 8 + ((i) != 0)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                          \
     } while (0)
 #define PIN(x) asm volatile("" : "+v"(x))
 #define PIN_ARR(arr, n)                              \
@@ -430,7 +442,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- loads: request everything the cycle needs, straight into LDS ------------
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const int lane = threadIdx.x & 63;
-    char* const region = lds_all + (threadIdx.x >> 6) * Stage<T>::bytes(NJ);
+    // wave-uniform by construction; say so, or every LDS destination goes through a VGPR + readfirstlane
+    char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * Stage<T>::bytes(NJ);
     const long Bp = a.Bpad;
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
     const long planeB = Bp * QB;  // bytes of one quad plane
@@ -481,7 +494,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
-    bool big = false;
     VFIK_WAIT_VM(0);  // constants, tool and q have landed
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
     STAMP(2);
@@ -496,18 +508,15 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 const int hi = *reinterpret_cast<const int*>(qrow + q_lds_off<T, NJ>(i * 8 + 4, lane));
                 q[i] = __hiloint2double(hi, lo);
             }
-            big = big || !(fabs(q[i]) <= SINCOS_FAST_MAX);
         }
     }
     {
+        // No libm fallback: the three-part reduction keeps full accuracy to |angle| ~ 1e5 rad and degrades
+        // smoothly beyond (error ~ |angle| * 1e-21); NaN / Inf propagate and are flagged VFIK_ST_NAN.
         double ang[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) ang[i] = q[i] + kl->dh[i].off;
         sincos_fast_n<NJ>(ang, sn, cs);
-    }
-    if (__any(big)) {  // out-of-range or NaN angle somewhere in the wave: full-range sincos
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) sincos(q[i] + kl->dh[i].off, &sn[i], &cs[i]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
@@ -614,7 +623,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lane, gq + 4 * k);
         speed = gq[15];
-        if (gq[12] != 0.0) {  // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, -]
+        {   // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, speedScale]
             double GR[9], Gp[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 for (int c = 0; c < 3; ++c) GR[3 * r + c] = gq[4 * r + c];
                 Gp[r] = gq[4 * r + 3];
             }
-            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, tot, sc);
+            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, kc->cos_slow, gq[12] != 0.0, tot, sc);
         }
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
@@ -636,9 +645,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             // object_feeder produces for point obstacles (object_feeder:317-334).  Empty slots carry
             // force 0.  Straight-line code per chunk of PRE slots: the slots interleave in the schedule.
             const int n0 = a.fast_order;
-            for (int c0 = 0;;) {
-                VFIK_WAIT_VM(0);  // this chunk's slots have landed
-                const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
+            auto chunk = [&](int ncur) {  // ncur: slots of this chunk that are in use (may exceed PRE)
                 double dx[PRE], dy[PRE], dz[PRE], di[PRE], rb[PRE], rp[PRE], fk[PRE];
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
@@ -671,20 +678,25 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                     const double k = fk[m] * fmin(rp[m], MAG_CAP) * di[m];
                     tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
                 }
-                c0 += PRE;
-                if (c0 >= a.slots_used) break;
-                // next chunk into the same rows: this wave's reads of them have returned
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            VFIK_WAIT_VM(0);  // the first chunk (requested during the kinematics) has landed
+            chunk(a.slots_used);
+            // further chunks reuse the same rows; kept out of line of the first so that the common
+            // (<= PRE slots) case is straight-line code with no loop-carried register shuffling
+            for (int c0 = PRE; c0 < a.slots_used; c0 += PRE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the rows have returned
 #pragma unroll
                 for (int idx = 0; idx < 2 * PRE; ++idx) {
                     const int m = c0 + (idx >> 1);
                     const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
                     stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
                 }
+                VFIK_WAIT_VM(0);
+                chunk(a.slots_used - c0);
             }
         } else {
             VFIK_WAIT_VM(0);  // (the staged slots are not used on the general path)
-            for (int m = 0; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, tot, sc);
+            for (int m = 0; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, kc->cos_slow, tot, sc);
         }
     }
     PIN_ARR(tot, 6);
@@ -1127,6 +1139,7 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.speed = p.speed_scale;
     c.lambda2 = p.lambda * p.lambda;
     c.rot_slow = p.rot_slowdown;
+    c.cos_slow = p.rot_slowdown > 0.0 && p.rot_slowdown < 3.14159265358979323846 ? std::cos(p.rot_slowdown) : -2.0;  // -2: always evaluate the angle
     c.null_gain = p.null_gain;
     c.lookahead = p.lookahead;
     c.max_vel = p.max_vel;

@@ -31,6 +31,33 @@ def _doubles(b):
     return [b.get(i).asDouble() for i in range(b.size())]
 
 
+def _emit(port, items, strict=True):
+    """One bottle: floats -> doubles, ints -> ints, str -> strings, list/tuple -> nested list of doubles."""
+    b = port.prepare()
+    b.clear()
+    for it in items:
+        if isinstance(it, (list, tuple)):
+            sub = b.addList()
+            for v in it:
+                sub.addDouble(float(v))
+        elif isinstance(it, str):
+            b.addString(it)
+        elif isinstance(it, (int, np.integer)) and not isinstance(it, bool):
+            b.addInt(int(it))
+        else:
+            b.addDouble(float(it))
+    port.write(strict)
+
+
+def _goal_entry(bottle, key=0):
+    """(xyz distance, rotation distance in rad) of object `key` in a /dmonitor/distOut bottle, else None."""
+    for i in range(bottle.size()):
+        line = bottle.get(i).asList()
+        if line is not None and line.get(0).asInt() == key:
+            return line.get(1).asDouble(), line.get(2).asDouble() * pi / 180.0
+    return None
+
+
 class HandleArmNew:
     def __init__(self, namespace="/0", module_name="/handle_arm", arm_namespace="/0", robot="/lwr", arm="/right", sim=True):
         self.sim = True
@@ -74,31 +101,11 @@ class HandleArmNew:
 
     def go_cart(self, frame):  # handlers.py:118-129
         self.cart_goal = frame
-        bottle = self.object_port.prepare()
-        bottle.clear()
-        bottle.addString("set")
-        bottle.addString("goal")
-        lst = bottle.addList()
-        for i in self.cart_goal:
-            lst.addDouble(i)
-        lst.addDouble(self.current_slowdown_distance)
-        self.object_port.writeStrict()
+        _emit(self.object_port, ["set", "goal", list(frame) + [self.current_slowdown_distance]])
         self.set_cartesian_control()
 
     def _write_yarp_port(self, port, data, strict=True):  # handlers.py:132-145
-        bottle = port.prepare()
-        bottle.clear()
-        for i in data:
-            if type(i) == float or isinstance(i, np.floating):
-                bottle.addDouble(float(i))
-            elif type(i) == int:
-                bottle.addInt(i)
-            elif type(i) == str:
-                bottle.addString(i)
-        if strict:
-            port.writeStrict()
-        else:
-            port.write()
+        _emit(port, [d for d in data if isinstance(d, (float, int, str, np.floating, np.integer))], strict)
 
     def go_joint(self, angles):
         self.joint_goal = angles
@@ -117,11 +124,9 @@ class HandleArmNew:
 
     def get_dist_cart_goal(self):  # handlers.py:163-177
         while True:
-            dists = self.distout_port.read(True)
-            for i in range(dists.size()):
-                item = dists.get(i).asList()
-                if item.get(0).asInt() == 0:  # main goal
-                    return [item.get(1).asDouble(), item.get(2).asDouble() * pi / 180.0]
+            entry = _goal_entry(self.distout_port.read(True))  # object 0 = main goal
+            if entry is not None:
+                return list(entry)
 
     def get_dist_joint_goal(self):
         bottle = self.bridge_encoders_port.read(True)
@@ -142,20 +147,10 @@ class HandleArmNew:
         self.set_controller_mixer(cart=False, null=False, joint=True)
 
     def set_wik_joint_weights(self, joint_weights):
-        bottle = self.vf_weight_port.prepare()
-        bottle.clear()
-        bottle.addString("j")
-        for w in joint_weights:
-            bottle.addDouble(w)
-        self.vf_weight_port.writeStrict()
+        _emit(self.vf_weight_port, ["j"] + [float(w) for w in joint_weights])
 
     def set_wik_cart_weights(self, cart_weights):
-        bottle = self.vf_weight_port.prepare()
-        bottle.clear()
-        bottle.addString("t")
-        for w in cart_weights:
-            bottle.addDouble(w)
-        self.vf_weight_port.writeStrict()
+        _emit(self.vf_weight_port, ["t"] + [float(w) for w in cart_weights])
 
     def set_tool(self, tool_frame):
         self._write_yarp_port(self.tool_port, [float(x) for x in tool_frame])
@@ -181,11 +176,7 @@ class HandleArm(object):
 
     def setTool(self, toolframe):
         """toolframe: 16 values (the reference takes a PyKDL Frame and flattens it, handlers.py:276-288)."""
-        bout = self.toolp.prepare()
-        bout.clear()
-        for i in toolframe:
-            bout.addDouble(float(i))
-        self.toolp.write(True)
+        _emit(self.toolp, [float(v) for v in toolframe])
 
     def set_stiffness(self, stiffness):
         bottle = self.stiffness_port.prepare()
@@ -205,71 +196,57 @@ class HandleArm(object):
         frame_list.addDouble(self.current_slowdown_distance)
         self.outp.write(True)
 
-    def gotoPos(self, pos):
-        self.current_frame[3], self.current_frame[7], self.current_frame[11] = pos[0], pos[1], pos[2]
+    def _place(self, pos=None, orient=None):
+        if pos is not None:
+            self.current_frame[3:12:4] = [float(pos[0]), float(pos[1]), float(pos[2])]
+        if orient is not None:
+            for row in range(3):
+                self.current_frame[4 * row:4 * row + 3] = [float(v) for v in orient[3 * row:3 * row + 3]]
         self.sendFrame()
 
+    def gotoPos(self, pos):
+        self._place(pos=pos)
+
     def setOrient(self, orient):
-        for i in range(3):
-            for j in range(3):
-                self.current_frame[j + 4 * i] = orient[j + i * 3]
-        self.sendFrame()
+        self._place(orient=orient)
 
     def getPose(self, blocking=True):
         pose_b = self.posep.read(blocking)
         return _doubles(pose_b) if pose_b is not None else None
 
     def gotoPose(self, pos, orient):
-        self.current_frame[3], self.current_frame[7], self.current_frame[11] = pos[0], pos[1], pos[2]
-        for i in range(3):
-            for j in range(3):
-                self.current_frame[j + 4 * i] = orient[j + i * 3]
-        self.sendFrame()
+        self._place(pos=pos, orient=orient)
 
     def gotoFrame(self, frame, wait=10.0, goal_precision=[], spin=None):
         """frame: 16 values; wait in seconds; goal_precision [trans, rot] (handlers.py:346-387).
         ``spin``: callable run while waiting (the in-process substitute for the other processes)."""
-        for i in range(len(frame)):
-            self.current_frame[i] = frame[i]
+        self.current_frame[:len(frame)] = [float(v) for v in frame]
         self.sendFrame()
-        init_time = cur_time = time.time()
-        difference = np.array([0.0, 0.0])
-        result = False
-        while self.goaldistp.getPendingReads():
+        deadline = time.time() + wait
+        difference, result = np.array([0.0, 0.0]), False
+        while self.goaldistp.getPendingReads():  # stale reports
             self.goaldistp.read(False)
-        if len(goal_precision) == 2 and wait > 0.0:
-            first_read = True
-            while cur_time - init_time < wait:
-                if spin is not None:
-                    spin()
-                b = self.goaldistp.read(False)
-                if b and not first_read:
-                    for i in range(b.size()):
-                        line = b.get(i).asList()
-                        if line.get(0).asInt() == 0:
-                            pos_dist = line.get(1).asDouble()
-                            orient_dist = line.get(2).asDouble() * pi / 180.0
-                    difference = np.array([pos_dist, orient_dist])
-                    if pos_dist < goal_precision[0] and orient_dist < goal_precision[1]:
-                        result = True
-                        break
-                first_read = False
-                if spin is None:
-                    time.sleep(0.01)
-                cur_time = time.time()
+        skip_first = True  # the reference discards the first report after sending the goal
+        while len(goal_precision) == 2 and wait > 0.0 and time.time() < deadline:
+            if spin is not None:
+                spin()
+            else:
+                time.sleep(0.01)
+            b = self.goaldistp.read(False)
+            if b is None:
+                continue
+            entry = None if skip_first else _goal_entry(b)
+            skip_first = False
+            if entry is not None:
+                difference = np.array(entry)
+                if entry[0] < goal_precision[0] and entry[1] < goal_precision[1]:
+                    result = True
+                    break
         return (result, difference)
 
     def gotThere(self):
-        b = self.goaldistp.read(True)
-        dist = 1000.0
-        if b:
-            for i in range(b.size()):
-                line = b.get(i).asList()
-                if line.get(0).asInt() == 0:
-                    dist = line.get(1).asDouble()
-            if dist < self.goal_threshold:
-                return True
-        return False
+        entry = _goal_entry(self.goaldistp.read(True))
+        return entry is not None and entry[0] < self.goal_threshold
 
     def gotoPosBlocking(self, pos, timeout=20):
         self.gotoPos(pos)
@@ -306,11 +283,7 @@ class HandleBridge(object):
         return _doubles(self.encoders_port.read())
 
     def _weights(self, vals):
-        bout = self.outp.prepare()
-        bout.clear()
-        for v in vals:
-            bout.addInt(v)
-        self.outp.write(True)
+        _emit(self.outp, [int(v) for v in vals])
 
     def joint_controller(self):
         self._weights([0, 0, 1, 0])
@@ -319,26 +292,17 @@ class HandleBridge(object):
         self._weights([1, 1, 0, 0])
 
     def torso_joints(self, cjoints):
-        if self.torso:
-            bout = self.torso_port.prepare()
-            bout.clear()
-            for i in cjoints:
-                bout.addInt(i)
-            self.torso_port.write(True)
-        else:
+        if not self.torso:
             print("There's no torso")
+            return
+        _emit(self.torso_port, [int(j) for j in cjoints])
 
     def set_VFW(self, type_of="joint", weights=[1] * 7):  # back compatibility
         print("deprecated, use set_weights instead")
         self.set_weights(type_of, weights)
 
     def set_weights(self, type_of="joint", weights=[1] * 7):
-        bout = self.VFW_port.prepare()
-        bout.clear()
-        bout.addString("t" if type_of == "task" else "j")
-        for w in weights:
-            bout.addDouble(w)
-        self.VFW_port.write(True)
+        _emit(self.VFW_port, ["t" if type_of == "task" else "j"] + [float(w) for w in weights])
 
 
 class HandleJController(object):
@@ -351,30 +315,24 @@ class HandleJController(object):
         yarp.Network.connect(prename + "/bridge/encoders", full_name + "/q")
 
     def set_ref_js(self, js, wait=0.0, goal_precision=[], spin=None):  # handlers.py:544-576
-        bout = self.outp.prepare()
-        bout.clear()
-        for i in js:
-            bout.addDouble(i)
-        self.outp.write(True)
-        init_time = cur_time = time.time()
         js = np.asarray(js, dtype=float)
-        difference = np.array([0.0] * len(js))
-        result = False
-        if len(goal_precision) == len(js) and wait != 0.0:
-            gp = np.array(goal_precision)
-            while (cur_time - init_time < wait) or wait == -1:
-                if spin is not None:
-                    spin()
-                b = self.inp.read(False)
-                if b:
-                    q = np.array(_doubles(b))
-                    difference = js - q
-                    if (((js - gp) <= q) * ((js + gp) >= q)).all():
-                        result = True
-                        break
-                if spin is None:
-                    time.sleep(0.01)
-                cur_time = time.time()
+        _emit(self.outp, js.tolist())
+        start = time.time()
+        difference, result = np.zeros(len(js)), False
+        if len(goal_precision) != len(js) or wait == 0.0:
+            return (result, difference)
+        tol = np.asarray(goal_precision, dtype=float)
+        while wait == -1 or time.time() - start < wait:  # wait == -1: until reached (handlers.py:559)
+            if spin is not None:
+                spin()
+            else:
+                time.sleep(0.01)
+            b = self.inp.read(False)
+            if b:
+                difference = js - np.array(_doubles(b))
+                if np.all(np.abs(difference) <= tol):
+                    result = True
+                    break
         return (result, difference)
 
 
