@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
     args = ap.parse_args()
 
@@ -136,6 +137,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary figure (never `value`): closed-loop rollout, K control cycles per launch with q integrated in
+    # registers -- what the cycle costs once the per-launch boundary is amortised
+    rollout = None
+    if args.rollout > 0:
+        q_end = torch.empty_like(q)
+        qd2 = torch.empty_like(qdot)
+        io_r = eng.make_io(q, qdot_out=qd2)
+        eng.rollout(io_r, args.rollout, 1e-3, q_out=q_end)
+        sync_all()
+        launches = 5
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(launches):
+            eng.rollout(io_r, args.rollout, 1e-3, q_out=q_end)
+        r1.record(stream)
+        sync_all()
+        r_ms = r0.elapsed_time(r1)
+        if world > 1:
+            t = torch.tensor([r_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r_ms = float(t.item())
+        rollout = {"cycles_per_launch": args.rollout, "launches": launches, "dt": 1e-3,
+                   "us_per_cycle": r_ms * 1e3 / (launches * args.rollout),
+                   "cycles_per_s": world * B * launches * args.rollout / (r_ms * 1e-3)}
+
     gathered = None
     if args.gather and world > 1:
         # optional collation of the per-rank results (NOT part of the control path): one all_gather
@@ -183,6 +209,8 @@ def main():
                                                                         "true" if flags & 1 else "false"),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle, "us_per_launch_hip_events": us_per_launch},
         }
+        if rollout is not None:
+            line["rollout"] = rollout
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(chain, params, w)
             line["cpu_baseline"]["numpy_ref_style_loop_cycles_per_s_1proc"] = numpy_loop_rate(chain, params, w)

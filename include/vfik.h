@@ -120,6 +120,17 @@ int vfik_step(vfik_handle* h, const vfik_io* io);
 int vfik_step_host(vfik_handle* h, const vfik_io* io);
 int vfik_sync(vfik_handle* h);
 
+/* Closed-loop rollout: n_cycles control cycles in ONE launch.  After each cycle the
+ * commanded velocity (what io->qdot_out reports) is integrated, q <- q + dt * qdot_out -- the role of
+ * the kinematic simulator `joint_sim` that `vfclik -s` wires behind the bridge (scripts/vfclik:99-103,
+ * scripts/bridge:136-139) -- and optionally clamped to the joint limits.  io->q is the start
+ * configuration; the outputs named in io are those of the LAST cycle; q_out[B][n] (may be NULL) receives
+ * the joint angles after it.  Field sets, tools, weights and /control stay fixed during the launch,
+ * as they do between two messages in the reference; the nullspace sign memory advances every cycle.
+ * Device pointers, asynchronous; vfik_rollout_host takes host pointers and synchronises. */
+int vfik_rollout(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);
+int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);
+
 /* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
  * host weights[K], device out[B][n].  Bit-exact with the reference's left-to-right sum. */
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out);

@@ -1,0 +1,92 @@
+"""Closed-loop rollout (vfik_rollout): K control cycles in one launch with q integrated on
+the device, against (a) the oracle stepped K times on the host with the same Euler update and (b) K
+single-cycle launches of the HIP path itself."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, engine, robots, synth
+
+    class E:
+        pass
+
+    e = E()
+    e.oc, e.abi, e.engine, e.robots, e.synth = oracle_c, _abi, engine, robots, synth
+    return e
+
+
+def _oracle_rollout(env, chain, params, w, K, dt, ctrl=None, clamp=False):
+    q = w["q"].copy()
+    states = env.oc.new_states(q.shape[0], chain.n) if params.flags & env.abi.F_NULLSPACE else None
+    status = np.zeros(q.shape[0], dtype=np.int32)
+    for _ in range(K):
+        ref = env.oc.cycle_batch(chain, params, q, w["fields"], w["nfields"], null_control=ctrl, states=states)
+        status |= ref["status"]
+        qn = q + dt * ref["qdot_out"]
+        if clamp:
+            qn = np.clip(qn, chain.q_lo, chain.q_hi)
+        last_q, q = q, qn
+    return q, ref, status
+
+
+@pytest.mark.parametrize("robot,nobs,flags", [("lwr", 8, 0), ("lwr", 3, 1 | 4), ("lwr_dual14", 12, 1 | 2 | 4), ("powercube6", 2, 4 | 8)])
+def test_rollout_matches_stepped_oracle(env, robot, nobs, flags):
+    chain = env.robots.by_name(robot)
+    B, K, dt = 1024, 40, 0.01
+    w = env.synth.make_workload(chain, B, nobs, seed=31, io_dtype=np.float64)
+    params = env.abi.default_params(flags=flags, max_vel=0.7)
+    ctrl = np.random.default_rng(5).uniform(-1, 1, (B, 4)) if (flags & 1) and chain.n == 7 else None
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=16, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    got = eng.rollout_host(w["q"], K, dt, null_control=ctrl, clamp=True, want=("qdot_out", "qdot_vf", "pose", "qdist", "status"))
+    q_ref, ref, st_ref = _oracle_rollout(env, chain, params, w, K, dt, ctrl, clamp=True)
+    assert np.abs(got["q"] - q_ref).max() < 1e-8, np.abs(got["q"] - q_ref).max()
+    for k in ("qdot_out", "qdot_vf", "pose", "qdist"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-7, (k, np.abs(got[k] - ref[k]).max())
+    assert np.array_equal(got["status"], st_ref)  # status bits accumulate over the cycles
+    assert np.abs(got["q"] - w["q"]).max() > 0.05   # the arms did move
+    eng.close()
+
+
+def test_rollout_equals_repeated_single_launches(env):
+    chain = env.robots.lwr()
+    B, K, dt = 4096, 25, 0.004
+    w = env.synth.make_workload(chain, B, 8, seed=32, io_dtype=np.float32)
+    f = env.abi
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER)
+    ctrl = np.random.default_rng(6).uniform(-1, 1, (B, 4)).astype(np.float32)
+    e1 = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=params)
+    e2 = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=params)
+    for e in (e1, e2):
+        e.set_fields(w["fields"], w["nfields"])
+    # float64 integration on the host between launches vs float64 integration in registers: the only
+    # difference is that the stepped path rounds q to float32 at every launch boundary
+    q = w["q"].astype(np.float64)
+    for _ in range(K):
+        out = e1.step_host(q.astype(np.float32), null_control=ctrl, want=("qdot_out",))
+        q = q.astype(np.float32).astype(np.float64) + dt * out["qdot_out"].astype(np.float64)
+    got = e2.rollout_host(w["q"], K, dt, null_control=ctrl, want=("qdot_out",))
+    assert np.abs(got["q"].astype(np.float64) - q).max() < 2e-5
+    assert np.abs(got["qdot_out"] - out["qdot_out"]).max() < 5e-4
+    e1.close()
+    e2.close()
+
+
+def test_rollout_argument_errors(env):
+    chain = env.robots.lwr()
+    eng = env.engine.Engine(chain, 64, io_dtype=np.float64, max_slots=2)
+    q = np.zeros((64, 7))
+    with pytest.raises(env.engine.VfikError, match="n_cycles"):
+        eng.rollout_host(q, 0, 0.01)
+    with pytest.raises(env.engine.VfikError):
+        eng.rollout_host(q, 10, float("nan"))
+    out = eng.rollout_host(q, 3, 0.01)  # no fields: nothing moves
+    assert np.all(out["q"] == 0.0) and np.all(out["qdot_out"] == 0.0)
+    eng.close()

@@ -80,7 +80,7 @@ struct vfik_handle {
     bool speed_set = false;
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
-    Scratch sc[10];
+    Scratch sc[12];
 };
 
 namespace {
@@ -490,16 +490,28 @@ int vfik_reset_state(vfik_handle* h) {
     return VFIK_OK;
 }
 
-int vfik_step(vfik_handle* h, const vfik_io* io) {
+static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out) {
     if (check_handle(h)) return VFIK_E_ARG;
-    if (!io || !io->q) return fail(VFIK_E_ARG, "vfik_step needs io->q");
+    if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
     HIP_TRY(hipSetDevice(h->device));
     vfik::KArgs a;
     fill_kargs(h, io, a);
+    a.n_cycles = n_cycles;
+    a.dt = dt;
+    a.clamp = clamp ? 1 : 0;
+    a.q_out = q_out;
     hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, h->stream);
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VFIK_OK;
+}
+
+int vfik_step(vfik_handle* h, const vfik_io* io) { return launch_cycles(h, io, 0, 0.0, 0, nullptr); }
+
+int vfik_rollout(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out) {
+    if (n_cycles < 1 || n_cycles > 1000000) return fail(VFIK_E_ARG, "n_cycles %d outside [1, 1e6]", n_cycles);
+    if (!std::isfinite(dt)) return fail(VFIK_E_ARG, "dt must be finite");
+    return launch_cycles(h, io, n_cycles, dt, clamp_to_limits, q_out);
 }
 
 int vfik_sync(vfik_handle* h) {
@@ -509,15 +521,15 @@ int vfik_sync(vfik_handle* h) {
     return VFIK_OK;
 }
 
-int vfik_step_host(vfik_handle* h, const vfik_io* io) {
+static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out_host) {
     if (check_handle(h)) return VFIK_E_ARG;
-    if (!io || !io->q) return fail(VFIK_E_ARG, "vfik_step_host needs io->q");
+    if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     HIP_TRY(hipSetDevice(h->device));
     const size_t B = h->B, n = h->n, e = h->esz;
     const void* hin[2] = {io->q, io->null_control};
     const size_t bin[2] = {B * n * e, B * VFIK_NULL_CONTROLS * e};
-    void* hout[8] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status};
-    const size_t bout[8] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t)};
+    void* hout[9] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host};
+    const size_t bout[9] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e};
     auto need = [&](int i, size_t bytes) -> void* {
         auto& s = h->sc[i];
         if (s.bytes < bytes) {
@@ -535,8 +547,8 @@ int vfik_step_host(vfik_handle* h, const vfik_io* io) {
             if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
             HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->stream));
         }
-    void* dout[8];
-    for (int i = 0; i < 8; ++i) {
+    void* dout[9];
+    for (int i = 0; i < 9; ++i) {
         dout[i] = hout[i] ? need(2 + i, bout[i]) : nullptr;
         if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
     }
@@ -544,12 +556,19 @@ int vfik_step_host(vfik_handle* h, const vfik_io* io) {
     d.q = din[0]; d.null_control = din[1];
     d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
     d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]);
-    int rc = vfik_step(h, &d);
+    const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 9; ++i)
         if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
+}
+
+int vfik_step_host(vfik_handle* h, const vfik_io* io) { return cycles_host(h, io, 0, 0.0, 0, nullptr); }
+
+int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out) {
+    if (n_cycles < 1) return fail(VFIK_E_ARG, "n_cycles must be >= 1");
+    return cycles_host(h, io, n_cycles, dt, clamp_to_limits, q_out);
 }
 
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out) {

@@ -90,6 +90,11 @@ struct KArgs {
     int* status;
     unsigned long long* stamps;  // diagnostic builds only (-DVFIK_STAMPS): [waves][8] s_memtime values
     const void* kc;              // KConst<n> in device memory
+    // closed-loop rollout (ROLL kernel variant): n_cycles control cycles per launch, q += dt * qdot_out
+    void* q_out;                 // [B][n] joint angles after the last cycle, or NULL
+    double dt;
+    int n_cycles;                // 0: ordinary single-cycle launch
+    int clamp;                   // keep q inside [q_lo, q_hi] after each integration step
 };
 
 // size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest

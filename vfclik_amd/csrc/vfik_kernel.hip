@@ -425,7 +425,10 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
 // PLAIN = the common configuration, decided on the host: all joints revolute, last fixed transform a
 // pure z-screw already absorbed, one identity tool for the batch, unit IK weights.  The general variant
 // carries the joint-type blends, the tool product, RefPoint and the weight scaling.
-template <typename T, int NJ, bool NULLSP, bool PLAIN>
+// ROLL = closed-loop rollout: a.n_cycles control cycles in one launch, the joint angles
+// integrated in registers (q += dt * qdot_out, the role of the external joint_sim, vfclik:99-103), the
+// field set read from LDS every cycle; one launch boundary and one set of loads per n_cycles cycles.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL>
 __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
@@ -510,6 +513,24 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             }
         }
     }
+    // values of the last evaluated cycle, for the outputs after the loop
+    double o_q[NJ], o_R[9], o_p[3], o_Rt[9], o_pt[3], o_v[3], o_w[3], o_qv[NJ], o_qn[NJ], o_qo[NJ];
+    // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
+    int sig_r = 1;
+    double lv_r[NJ];
+    if constexpr (NULLSP && ROLL) {  // (a single-cycle launch reads the state where it is used: fewer live registers)
+        sig_r = a.sig[arm];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
+    }
+    const int ncyc = ROLL ? a.n_cycles : 1;
+    for (int cyc = 0; cyc < ncyc; ++cyc) {
+    const bool first = !ROLL || cyc == 0;
+    if (ROLL && !first && a.slots_used > PRE) {  // the rows hold the last chunk of the previous cycle
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int idx = 0; idx < 2 * PRE; ++idx) issue_slot_quad(idx);
+    }
     {
         // No libm fallback: the three-part reduction keeps full accuracy to |angle| ~ 1e5 rad and degrades
         // smoothly beyond (error ~ |angle| * 1e-21); NaN / Inf propagate and are flagged VFIK_ST_NAN.
@@ -518,8 +539,10 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) ang[i] = q[i] + kl->dh[i].off;
         sincos_fast_n<NJ>(ang, sn, cs);
     }
+    if (first) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
+        for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
+    }
     double R[9], p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -556,7 +579,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
-            if (i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
+            if (first && i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
     }
     if (!PLAIN) {   // trailing z-screw of the last fixed transform
         const double tc = kl->tail_c, ts = kl->tail_s, te = kl->tail_e;
@@ -879,24 +902,34 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 if (!found && fabs(u[i]) > 1e-9) { found = true; sg = u[i] > 0.0 ? -1.0 : 1.0; }
             }
             // sign continuity against the previous cycle (nullspace:101-105)
-            int sig = a.sig[arm];
+            if constexpr (!ROLL) {
+                sig_r = a.sig[arm];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
+            }
+            int sig = sig_r;
             double dm = 0.0, dp = 0.0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 u[i] *= sg;
-                const double lv = a.lastvec[i * Bs + arm];
+                const double lv = lv_r[i];
                 const double x = sig * u[i] - lv, y = sig * u[i] + lv;
                 dm += x * x; dp += y * y;
             }
             if (sqrt(dm) > sqrt(dp)) sig = -sig;
-            a.sig[arm] = sig;
+            sig_r = sig;
             double c0 = 0.0;
             if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 u[i] *= sig;
-                a.lastvec[i * Bs + arm] = u[i];
+                lv_r[i] = u[i];
                 qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
+            }
+            if constexpr (!ROLL) {
+                a.sig[arm] = sig_r;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
             }
         } else if (nullity >= 2) {
             status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
@@ -969,6 +1002,35 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     for (int i = 0; i < NJ; ++i) nan = nan || (qo[i] != qo[i]);
     if (nan) status |= VFIK_ST_NAN;
 
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) { o_q[i] = q[i]; o_qv[i] = qv[i]; o_qn[i] = qn[i]; o_qo[i] = qo[i]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o_R[k] = R[k]; o_Rt[k] = Rt[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o_p[k] = p[k]; o_pt[k] = pt[k]; o_v[k] = v[k]; o_w[k] = w[k]; }
+    if (ROLL) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            q[i] = __builtin_fma(a.dt, qo[i], q[i]);
+            if (a.clamp) q[i] = fmin(fmax(q[i], kc->q_lo[i]), kc->q_hi[i]);
+        }
+    }
+    }  // cycles of this launch
+    if constexpr (NULLSP && ROLL) {
+        a.sig[arm] = sig_r;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
+    }
+    if (ROLL && a.q_out) {
+        T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) o[i] = (T)q[i];
+    }
+    // the outputs below are those of the last evaluated cycle
+    double (&qo)[NJ] = o_qo; double (&qv)[NJ] = o_qv; double (&qn)[NJ] = o_qn; double (&qe)[NJ] = o_q;
+    double (&R)[9] = o_R; double (&Rt)[9] = o_Rt; double (&p)[3] = o_p; double (&pt)[3] = o_pt;
+    double (&v)[3] = o_v; double (&w)[3] = o_w;
+
     // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
     if (a.qdot_out) {
         T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
@@ -1013,7 +1075,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     if (a.qdist) {
         T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+        for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(qe[i] - kc->q_mid[i]) * kc->inv_half[i]);
 
     }
     if (a.status) a.status[arm] = status;
@@ -1031,6 +1093,12 @@ __global__ void __launch_bounds__(256) mix_kernel(const T* cmds, const double* w
     out[i] = (T)acc;
 }
 
+template <typename T, int NJ, bool NS, bool PL>
+void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    if (a.n_cycles > 0) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true>), grid, blk, lds, stream, a);
+    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false>), grid, blk, lds, stream, a);
+}
+
 template <typename T, int NJ>
 hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream) {
     KArgs a = a0;
@@ -1039,15 +1107,34 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream) {
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     const bool ns = a.flags & VFIK_F_NULLSPACE;
     if (a.plain) {
-        if (ns) hipLaunchKernelGGL((cycle_kernel<T, NJ, true, true>), grid, blk, lds, stream, a);
-        else hipLaunchKernelGGL((cycle_kernel<T, NJ, false, true>), grid, blk, lds, stream, a);
+        if (ns) launch_v<T, NJ, true, true>(a, grid, blk, lds, stream);
+        else launch_v<T, NJ, false, true>(a, grid, blk, lds, stream);
     } else {
-        if (ns) hipLaunchKernelGGL((cycle_kernel<T, NJ, true, false>), grid, blk, lds, stream, a);
-        else hipLaunchKernelGGL((cycle_kernel<T, NJ, false, false>), grid, blk, lds, stream, a);
+        if (ns) launch_v<T, NJ, true, false>(a, grid, blk, lds, stream);
+        else launch_v<T, NJ, false, false>(a, grid, blk, lds, stream);
     }
     return hipGetLastError();
 }
 
+}  // namespace
+
+// The library is built from this one source compiled several times (csrc/Makefile): once per joint
+// count with -DVFIK_ONLY_NJ=<n> (the kernels of that n, in parallel make jobs) and once with
+// -DVFIK_DISPATCH (launch dispatch, mixer kernel, host-side constant preparation).
+#ifdef VFIK_ONLY_NJ
+#define VFIK_CAT2(a, b) a##b
+#define VFIK_CAT(a, b) VFIK_CAT2(a, b)
+hipError_t VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ)(int io_dtype, const KArgs& kargs, int block, hipStream_t stream) {
+    return io_dtype == 32 ? launch_t<float, VFIK_ONLY_NJ>(kargs, block, stream) : launch_t<double, VFIK_ONLY_NJ>(kargs, block, stream);
+}
+}  // namespace vfik
+#else  // VFIK_DISPATCH
+
+#define X(n) hipError_t launch_cycle_nj##n(int io_dtype, const KArgs& kargs, int block, hipStream_t stream);
+VFIK_NJ_LIST
+#undef X
+
+namespace {
 // ------------------------------------------------------------------------------------------------
 // host: z-normal form -> DH form.  Every fixed transform factors as
 //     B = Rz(theta) Tz(d) Tx(a) Rx(alpha) Rz(phi) Tz(e)          (ZXZ Euler angles + common normal)
@@ -1165,7 +1252,7 @@ uint32_t supported_joints_mask() {
 
 hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream) {
     switch (nj) {
-#define X(n) case n: return io_dtype == 32 ? launch_t<float, n>(kargs, block, stream) : launch_t<double, n>(kargs, block, stream);
+#define X(n) case n: return launch_cycle_nj##n(io_dtype, kargs, block, stream);
         VFIK_NJ_LIST
 #undef X
         default: return hipErrorInvalidValue;
@@ -1204,3 +1291,4 @@ hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K
 }
 
 }  // namespace vfik
+#endif  // VFIK_ONLY_NJ / VFIK_DISPATCH

@@ -63,6 +63,8 @@ def load_library(path=None):
         "vfik_step": (C.c_int, [H, C.POINTER(IO)]),
         "vfik_step_host": (C.c_int, [H, C.POINTER(IO)]),
         "vfik_sync": (C.c_int, [H]),
+        "vfik_rollout": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
+        "vfik_rollout_host": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
         "vfik_mix": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "vfik_dev_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_dev_free": (C.c_int, [H, C.c_void_p]),
@@ -222,6 +224,31 @@ class Engine:
             setattr(io, k, out[k].ctypes.data)
         self._chk(self.lib.vfik_step_host(self.h, C.byref(io)))
         return out
+
+    def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",)):
+        """n_cycles control cycles in one launch with q integrated on the device.
+        Returns the outputs of the last cycle plus ``q`` = joint angles after it."""
+        q = np.ascontiguousarray(q, dtype=self.io_dtype)
+        if q.shape != (self.batch, self.n):
+            raise ValueError("q must be (%d, %d), got %s" % (self.batch, self.n, q.shape))
+        io = IO()
+        io.q = q.ctypes.data
+        keep = [q]
+        if null_control is not None:
+            nc = np.ascontiguousarray(null_control, dtype=self.io_dtype)
+            io.null_control = nc.ctypes.data
+            keep.append(nc)
+        out = {}
+        for k in want:
+            out[k] = np.zeros(self.batch, dtype=np.int32) if k == "status" else np.zeros(self._shape(k), dtype=self.io_dtype)
+            setattr(io, k, out[k].ctypes.data)
+        out["q"] = np.zeros((self.batch, self.n), dtype=self.io_dtype)
+        self._chk(self.lib.vfik_rollout_host(self.h, C.byref(io), int(n_cycles), float(dt), 1 if clamp else 0, out["q"].ctypes.data))
+        return out
+
+    def rollout(self, io, n_cycles, dt, q_out=None, clamp=False):
+        """Asynchronous device-pointer form of :meth:`rollout_host`."""
+        self._chk(self.lib.vfik_rollout(self.h, C.byref(io), int(n_cycles), float(dt), 1 if clamp else 0, C.c_void_p(_ptr(q_out))))
 
     def make_io(self, q, null_control=None, **outs):
         """IO block from device pointers (torch tensors on this device, or raw addresses)."""
