@@ -668,8 +668,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             // object_feeder produces for point obstacles (object_feeder:317-334).  Empty slots carry
             // force 0.  Straight-line code per chunk of PRE slots: the slots interleave in the schedule.
             const int n0 = a.fast_order;
-            auto chunk = [&](int ncur) {  // ncur: slots of this chunk that are in use (may exceed PRE)
-                double dx[PRE], dy[PRE], dz[PRE], di[PRE], rb[PRE], rp[PRE], fk[PRE];
+            // One chunk = PRE slots: read them out of LDS, then -- before the arithmetic -- request the
+            // next chunk into the same rows, so that its latency hides behind this chunk's math.
+            auto chunk = [&](int c0) {
+                const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
+                double dx[PRE], dy[PRE], dz[PRE], rs[PRE], fk[PRE];
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
                     double s0[4], s1[4];
@@ -678,12 +681,26 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                     dx[m] = s0[0] - pt[0];
                     dy[m] = s0[1] - pt[1];
                     dz[m] = s0[2] - pt[2];
+                    rs[m] = s0[3] + s1[0];
+                    fk[m] = m < ncur ? s1[2] : 0.0;
+                }
+                if (c0 + PRE < a.slots_used) {  // wave-uniform
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the rows have returned
+#pragma unroll
+                    for (int idx = 0; idx < 2 * PRE; ++idx) {
+                        const int m = c0 + PRE + (idx >> 1);
+                        const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+                        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+                    }
+                }
+                double di[PRE], rb[PRE], rp[PRE];
+#pragma unroll
+                for (int m = 0; m < PRE; ++m) {
                     double D;
                     sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
                     di[m] = fmin(di[m], 1.0 / D_FLOOR);
-                    rb[m] = (s0[3] + s1[0]) * di[m];
+                    rb[m] = rs[m] * di[m];
                     rp[m] = 1.0;
-                    fk[m] = m < ncur ? s1[2] : 0.0;
                 }
                 for (int e = n0; e;) {  // square-and-multiply, all slots in lock step
                     if (e & 1) {
@@ -703,19 +720,12 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 }
             };
             VFIK_WAIT_VM(0);  // the first chunk (requested during the kinematics) has landed
-            chunk(a.slots_used);
-            // further chunks reuse the same rows; kept out of line of the first so that the common
-            // (<= PRE slots) case is straight-line code with no loop-carried register shuffling
+            chunk(0);
+            // further chunks: kept out of line of the first so that the common (<= PRE slots) case is
+            // straight-line code with no loop-carried register shuffling
             for (int c0 = PRE; c0 < a.slots_used; c0 += PRE) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the rows have returned
-#pragma unroll
-                for (int idx = 0; idx < 2 * PRE; ++idx) {
-                    const int m = c0 + (idx >> 1);
-                    const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-                    stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
-                }
                 VFIK_WAIT_VM(0);
-                chunk(a.slots_used - c0);
+                chunk(c0);
             }
         } else {
             VFIK_WAIT_VM(0);  // (the staged slots are not used on the general path)
