@@ -110,6 +110,8 @@ typedef struct vfik_io {
     void* v6;                 /* out [B][6]   field twist before RefPoint (vf:346-347; /vector_out) */
     void* qdist;              /* out [B][n]   distToCenter (debug_jointlimits:65-67), not x100 */
     int32_t* status;          /* out [B]      VFIK_ST_* */
+    void* goal_dist;          /* out [B][2]   xyz distance and rotation angle in DEGREES to the goal: the object-0
+                                 entry of /dmonitor/distOut (monitor_distance:76-84,161-172) */
 } vfik_io;
 
 /* One control cycle for the whole batch -- the loop bodies of vf:311-466, nullspace:162-184,
@@ -130,6 +132,14 @@ int vfik_sync(vfik_handle* h);
  * Device pointers, asynchronous; vfik_rollout_host takes host pointers and synchronises. */
 int vfik_rollout(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);
 int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);
+
+/* Tracking-error estimator of scripts/vf (vf:349-428) for the batch: feed it, once per cycle, the tool
+ * poses and field twists that vfik_step produced (device pointers pose[B][16], v6[B][6]); out[B][8] gets
+ * vel_diff_angle, rot_diff_angle, ext_vel_mag_corr, ext_rot_mag_corr, cmd_vel_mag_corr, cmd_rot_mag_corr,
+ * ext_int_diff, arm_tracking (the /track_error bottle, vf:418-427); zeros until the 6th frame (vf:354).
+ * Per-arm history (previous frame, last 4 commands) lives in the handle; vfik_track_reset clears it. */
+int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out);
+int vfik_track_reset(vfik_handle* h);
 
 /* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
  * host weights[K], device out[B][n].  Bit-exact with the reference's left-to-right sum. */

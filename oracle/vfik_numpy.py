@@ -479,3 +479,46 @@ class ArmCycle:
         return dict(qdot_vf=np.array(qdot_vf), qdot_null=np.array(qdot_null), qdot_out=np.array(out),
                     pose=np.array(frame), pose_nt=np.array(kdlFrameToList(kdlframe)),
                     v6=np.concatenate([velPos, velRot]), qdist=np.array(qdist), status=status)
+
+
+# ---------------------------------------------------------------------------------------------
+# observers
+# ---------------------------------------------------------------------------------------------
+class TrackingError:
+    """The tracking-error estimator inside scripts/vf (vf:156-160,349-428), one arm."""
+    cmd_buffer_size, frame_list_size, check_delay = 4, 5, 4  # vf:158-160
+
+    def __init__(self):
+        self.frame_list, self.cmd_buffer = [], []
+
+    def update(self, newkdlframe, velPos, velRot):
+        """Returns the 8 values of the /track_error bottle, or None while the history is short."""
+        self.cmd_buffer.append([np.asarray(velPos, float), np.asarray(velRot, float)])
+        if len(self.cmd_buffer) > self.cmd_buffer_size:
+            self.cmd_buffer.pop(0)
+        self.frame_list.append(newkdlframe)
+        if len(self.frame_list) <= self.frame_list_size:
+            return None
+        self.frame_list.pop(0)
+        ext = diff(self.frame_list[-2], self.frame_list[-1])
+        cmd = self.cmd_buffer[len(self.cmd_buffer) - self.check_delay]
+        ext_vel_mag, cmd_vel_mag = norm(ext.vel), norm(cmd[0])
+        ext_vel = ext.vel / ext_vel_mag if ext_vel_mag > 0 else np.array([1.0, 0, 0])
+        cmd_vel = cmd[0] / cmd_vel_mag if cmd_vel_mag > 0 else np.array([1.0, 0, 0])
+        vel_diff_angle = abs(math.acos(min(1.0, max(-1.0, float(cmd_vel @ ext_vel)))))
+        ext_rot_mag, cmd_rot_mag = norm(ext.rot), norm(cmd[1])
+        ext_rot = ext.rot / ext_rot_mag if ext_rot_mag > 0 else np.array([1.0, 0, 0])
+        cmd_rot = cmd[1] / cmd_rot_mag if cmd_rot_mag > 0 else np.array([1.0, 0, 0])
+        rot_diff_angle = abs(math.acos(min(1.0, max(-1.0, float(cmd_rot @ ext_rot)))))
+        loop_freq, tracking_th = 150, 0.10  # vf:408-409
+        ev, er = ext_vel_mag * loop_freq, ext_rot_mag * loop_freq
+        cr, cv = cmd_rot_mag / 5.0, cmd_vel_mag * 1.0
+        ext_int_diff = abs((cv + cr) - (ev + er))
+        return np.array([vel_diff_angle, rot_diff_angle, ev, er, cv, cr, ext_int_diff, float(ext_int_diff < tracking_th)])
+
+
+def goal_distance(pose16, goal16):
+    """The object-0 entry of /dmonitor/distOut: xyz distance and orientLength in degrees
+    (scripts/monitor_distance:76-84,161-167)."""
+    F, G = listToKdlFrame(pose16), listToKdlFrame(goal16)
+    return norm(F.p - G.p), 180.0 * norm(rot_log(F.M, G.M)) / math.pi

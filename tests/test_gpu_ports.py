@@ -157,3 +157,36 @@ def test_closed_loop_reaches_the_goal(net):
     assert reached.mean() > 0.8, reached.mean()        # joint limits / singular poses stop some arms
     assert np.median(d) < 1e-3 and np.median(d0) > 0.3
     eng.close()
+
+
+def test_goto_frame_blocks_until_the_monitor_reports_arrival(net):
+    """HandleArm.gotoFrame (handlers.py:346-387) driven by /dmonitor/distOut from the batched cycle, with a
+    kinematic simulator in the spin callback (q += dt * mixed command)."""
+    yarp = net
+    from vfclik_amd import _abi, robots
+    from vfclik_amd.handlers import HandleArm
+    from vfclik_amd.object_feeder import ObjectFeeder
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    base = "/lwr/right"
+    params = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER | _abi.F_LIMITER, max_vel=2.0)
+    cc = ControlCycleBatch(chain, [base], io_dtype=np.float64, params=params)
+    feeder = ObjectFeeder(base)
+    h = HandleArm(base)
+    enc = _open(yarp, "/sim/encoders")
+    yarp.Network.connect("/sim/encoders", base + "/vectorField/qIn")
+    state = {"q": np.array([0.1, -0.6, 0.3, 1.2, 0.2, -0.9, 0.0]), "cycles": 0}
+    goal = chain.fk(np.array([0.4, -0.3, 0.5, 1.0, -0.2, -0.7, 0.3]))[0].reshape(16)
+
+    def spin():
+        feeder.spin_once()
+        _send(enc, state["q"])
+        if cc.cycle()[0]:
+            state["q"] = state["q"] + 0.01 * cc.last["qdot_out"][0]
+            state["cycles"] += 1
+
+    ok, diff = h.gotoFrame([float(x) for x in goal], wait=20.0, goal_precision=[0.005, 0.05], spin=spin)
+    assert ok, (diff, state["cycles"])
+    assert diff[0] < 0.005 and diff[1] < 0.05 and state["cycles"] > 20
+    cc.close()
+    feeder.close()

@@ -201,3 +201,20 @@ def test_default_params_match_reference_constants():
     p = _abi.default_params()
     assert p.speed_scale == 1.0 and p.null_gain == 0.5 and p.lookahead == 0.3  # vf:136, nullspace:62,121
     assert list(p.mix_w) == [1.0, 1.0, 0.0, 0.0, 0.0, 0.0]                        # bridge:596
+
+
+def test_tracking_state_majority_vote():
+    from vfclik_amd.vf_module import TrackingState
+    ts = TrackingState()
+    msgs = []
+    for k in range(25):   # far from the goal and following the command
+        msgs += ts.update(0.5, 30.0, 0.01, 0.01)
+    assert msgs == [("xyz", "follow"), ("rot", "follow")]   # reported once, when the vote over 20 samples flips
+    msgs = []
+    for k in range(25):   # far and NOT following
+        msgs += ts.update(0.5, 30.0, 0.5, 0.5)
+    assert msgs == [("xyz", "not follow"), ("rot", "not follow")]
+    msgs = []
+    for k in range(25):   # arrived
+        msgs += ts.update(0.001, 0.2, 0.5, 0.5)
+    assert msgs == [("xyz", "on goal"), ("rot", "on goal")]

@@ -68,6 +68,7 @@ struct vfik_handle {
     int* d_sig = nullptr;      // [B]
     double* d_mixw = nullptr;  // [16]
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    double* d_track = nullptr;  // tracking-error history [38][B], allocated on first use
     void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
     size_t dev_bytes = 0;
@@ -80,7 +81,7 @@ struct vfik_handle {
     bool speed_set = false;
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
-    Scratch sc[12];
+    Scratch sc[14];
 };
 
 namespace {
@@ -168,6 +169,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.v6 = io->v6;
     a.qdist = io->qdist;
     a.status = io->status;
+    a.goal_dist = io->goal_dist;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -283,7 +285,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -528,8 +530,8 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
     const size_t B = h->B, n = h->n, e = h->esz;
     const void* hin[2] = {io->q, io->null_control};
     const size_t bin[2] = {B * n * e, B * VFIK_NULL_CONTROLS * e};
-    void* hout[9] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host};
-    const size_t bout[9] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e};
+    void* hout[10] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host, io->goal_dist};
+    const size_t bout[10] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e};
     auto need = [&](int i, size_t bytes) -> void* {
         auto& s = h->sc[i];
         if (s.bytes < bytes) {
@@ -547,18 +549,18 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
             if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
             HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->stream));
         }
-    void* dout[9];
-    for (int i = 0; i < 9; ++i) {
+    void* dout[10];
+    for (int i = 0; i < 10; ++i) {
         dout[i] = hout[i] ? need(2 + i, bout[i]) : nullptr;
         if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
     }
     vfik_io d{};
     d.q = din[0]; d.null_control = din[1];
     d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
-    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]);
+    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[9];
     const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < 10; ++i)
         if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
@@ -569,6 +571,23 @@ int vfik_step_host(vfik_handle* h, const vfik_io* io) { return cycles_host(h, io
 int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out) {
     if (n_cycles < 1) return fail(VFIK_E_ARG, "n_cycles must be >= 1");
     return cycles_host(h, io, n_cycles, dt, clamp_to_limits, q_out);
+}
+
+int vfik_track_reset(vfik_handle* h) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->d_track) HIP_TRY(hipMemsetAsync(h->d_track, 0, (size_t)38 * h->B * sizeof(double), h->stream));
+    return VFIK_OK;
+}
+
+int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!pose || !v6 || !out) return fail(VFIK_E_ARG, "vfik_track_error: pose, v6 and out are required");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->d_track && dev_alloc(h, (void**)&h->d_track, (size_t)38 * h->B * sizeof(double), true)) return VFIK_E_HIP;
+    hipError_t e = vfik::launch_track(h->io_dtype, pose, v6, h->d_track, out, h->B, h->stream);
+    if (e != hipSuccess) return fail(VFIK_E_HIP, "track launch: %s", hipGetErrorString(e));
+    return VFIK_OK;
 }
 
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out) {

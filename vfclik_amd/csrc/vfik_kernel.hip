@@ -251,7 +251,7 @@ __device__ __forceinline__ void rot_axis_angle(const double* R, const double* G,
 // `on` masks the whole contribution (goal block absent): selects instead of a branch.
 __device__ __forceinline__ void attractor(const double* R, const double* p, const double* GR, const double* Gp,
                                           double slow, double force, double rot_slow, double cos_slow, bool on,
-                                          double* tot, double* sc) {
+                                          double* tot, double* sc, double* dist = nullptr) {
     const double dx = Gp[0] - p[0], dy = Gp[1] - p[1], dz = Gp[2] - p[2];
     double D, Dinv;
     sqrt_rsqrt(dx * dx + dy * dy + dz * dz, D, Dinv);
@@ -266,6 +266,7 @@ __device__ __forceinline__ void attractor(const double* R, const double* p, cons
     const double s1 = rot_slow > 0.0 ? fmin(1.0, th * rcp_nr(rot_slow)) : 1.0;
     sc[0] *= on ? s0 : 1.0;
     sc[1] *= on ? s1 : 1.0;
+    if (dist) { dist[0] = D; dist[1] = th; }
 }
 
 // Element e (0..7) of slot m of this lane's arm in the quad-plane layout (vfik_kernel.h): plane
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
     // values of the last evaluated cycle, for the outputs after the loop
-    double o_q[NJ], o_R[9], o_p[3], o_Rt[9], o_pt[3], o_v[3], o_w[3], o_qv[NJ], o_qn[NJ], o_qo[NJ];
+    double o_q[NJ], o_R[9], o_p[3], o_Rt[9], o_pt[3], o_v[3], o_w[3], o_qv[NJ], o_qn[NJ], o_qo[NJ], o_gd[2];
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
     double lv_r[NJ];
@@ -639,6 +640,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 
     // ---------------- A5: vector field at the tool pose (vf:276-293,344-347) -------------------
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
+    double gdist[2] = {0.0, 0.0};  // distance and rotation angle to the goal (monitor_distance:161-167)
     double speed;  // this arm's speedScale (vf:134-137,197-207), 4th component of the goal block's last quad
     VFIK_WAIT_VM(N_SLOT);  // goal block has landed
     {
@@ -654,7 +656,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 for (int c = 0; c < 3; ++c) GR[3 * r + c] = gq[4 * r + c];
                 Gp[r] = gq[4 * r + 3];
             }
-            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, kc->cos_slow, gq[12] != 0.0, tot, sc);
+            // a.goal_dist requested: the angle is needed whatever its size (cos_slow = -2 forces atan2)
+            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, a.goal_dist ? -2.0 : kc->cos_slow, gq[12] != 0.0, tot, sc, gdist);
         }
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
@@ -1018,6 +1021,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     for (int k = 0; k < 9; ++k) { o_R[k] = R[k]; o_Rt[k] = Rt[k]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o_p[k] = p[k]; o_pt[k] = pt[k]; o_v[k] = v[k]; o_w[k] = w[k]; }
+    o_gd[0] = gdist[0]; o_gd[1] = gdist[1];
     if (ROLL) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
@@ -1088,6 +1092,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(qe[i] - kc->q_mid[i]) * kc->inv_half[i]);
 
     }
+    if (a.goal_dist) {  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
+        T* o = static_cast<T*>(a.goal_dist) + (long)arm * 2;
+        o[0] = (T)o_gd[0];
+        o[1] = (T)(o_gd[1] * 57.295779513082320877);
+    }
     if (a.status) a.status[arm] = status;
     STAMP(7);
 }
@@ -1101,6 +1110,80 @@ __global__ void __launch_bounds__(256) mix_kernel(const T* cmds, const double* w
     double acc = 0.0;
     for (int k = 0; k < K; ++k) acc = mac_unfused(acc, (double)cmds[k * chan_stride + i], w[k]);
     out[i] = (T)acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tracking-error estimator of scripts/vf (vf:349-428), batched, as its own small kernel (a diagnostic:
+// it never feeds qdot).  Per arm it keeps the previous tool frame, the last 4 commanded twists and a
+// frame counter; from the 6th frame on (frame_list longer than 5, vf:354) it compares the twist
+// MEASURED between the two latest frames, scaled by the assumed 150 Hz robot loop (vf:408-411), with
+// the twist COMMANDED check_delay = 4 cycles earlier (vf:363): direction angles, corrected magnitudes,
+// |difference| and arm_tracking = difference < 0.10.  state: [38][B] doubles (12 frame, 24 commands,
+// count, -).  out: [B][8] = vel_diff_angle, rot_diff_angle, ext_vel_mag_corr, ext_rot_mag_corr,
+// cmd_vel_mag_corr, cmd_rot_mag_corr, ext_int_diff, arm_tracking (vf:418-427); zeros until the 6th frame.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) track_kernel(const T* pose, const T* v6, double* st, T* out, int B) {
+    const int arm = blockIdx.x * blockDim.x + threadIdx.x;
+    if (arm >= B) return;
+    const long Bs = B;
+    double F[12], P[12], cmd[4][6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { F[k] = (double)pose[(long)arm * 16 + k]; P[k] = st[k * Bs + arm]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cmd[j][k] = st[(12 + 6 * j + k) * Bs + arm];
+    const double cnt = st[36 * Bs + arm];  // frames seen before this one
+    // cmd_buffer.append(...); keep the last 4 (vf:350-352): after the shift cmd[0] is the oldest
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cmd[j][k] = cmd[j + 1][k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cmd[3][k] = (double)v6[(long)arm * 6 + k];
+    double res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cnt >= 5.0) {  // len(frame_list) > frame_list_size (vf:354)
+        // ext_diff = PyKDL.diff(previous frame, this frame): vel = dp, rot = log(R_b R_a^T) in the base frame
+        double ev[3] = {F[3] - P[3], F[7] - P[7], F[11] - P[11]};
+        double Ra[9], Rb[9], ax[3], th;
+        bool has_axis;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { Ra[3 * r + c] = P[4 * r + c]; Rb[3 * r + c] = F[4 * r + c]; }
+        rot_axis_angle(Ra, Rb, -2.0, ax, th, has_axis);
+        const double ext_vel_mag = sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+        const double ext_rot_mag = has_axis ? th : 0.0;
+        // the command issued check_delay = 4 cycles ago is the oldest entry of the full buffer (vf:363)
+        const double* c = cmd[0];
+        const double cmd_vel_mag = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double cmd_rot_mag = sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]);
+        double eu[3] = {1, 0, 0}, cu[3] = {1, 0, 0}, er[3] = {1, 0, 0}, cr[3] = {1, 0, 0};  // vf:365-374,390-399
+        if (ext_vel_mag > 0.0) for (int k = 0; k < 3; ++k) eu[k] = ev[k] / ext_vel_mag;
+        if (cmd_vel_mag > 0.0) for (int k = 0; k < 3; ++k) cu[k] = c[k] / cmd_vel_mag;
+        if (ext_rot_mag > 0.0) for (int k = 0; k < 3; ++k) er[k] = ax[k];
+        if (cmd_rot_mag > 0.0) for (int k = 0; k < 3; ++k) cr[k] = c[3 + k] / cmd_rot_mag;
+        const double vd = fmin(1.0, fmax(-1.0, cu[0] * eu[0] + cu[1] * eu[1] + cu[2] * eu[2]));
+        const double rd = fmin(1.0, fmax(-1.0, cr[0] * er[0] + cr[1] * er[1] + cr[2] * er[2]));
+        res[0] = fabs(acos(vd));
+        res[1] = fabs(acos(rd));
+        res[2] = ext_vel_mag * 150.0;   // loop_freq (vf:408)
+        res[3] = ext_rot_mag * 150.0;
+        res[4] = cmd_vel_mag;
+        res[5] = cmd_rot_mag / 5.0;     // vf:412
+        res[6] = fabs((res[4] + res[5]) - (res[2] + res[3]));
+        res[7] = res[6] < 0.10 ? 1.0 : 0.0;  // tracking_th (vf:409,416)
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[(long)arm * 8 + k] = (T)res[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st[k * Bs + arm] = F[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st[(12 + 6 * j + k) * Bs + arm] = cmd[j][k];
+    st[36 * Bs + arm] = cnt + 1.0;
 }
 
 template <typename T, int NJ, bool NS, bool PL>
@@ -1300,5 +1383,19 @@ hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K
     return hipGetLastError();
 }
 
+}  // namespace vfik
+
+namespace vfik {
+hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, int B, hipStream_t stream) {
+    const int block = 256;
+    const dim3 grid((B + block - 1) / block), blk(block);
+    if (io_dtype == 32)
+        hipLaunchKernelGGL(track_kernel<float>, grid, blk, 0, stream, static_cast<const float*>(pose), static_cast<const float*>(v6),
+                           state, static_cast<float*>(out), B);
+    else
+        hipLaunchKernelGGL(track_kernel<double>, grid, blk, 0, stream, static_cast<const double*>(pose),
+                           static_cast<const double*>(v6), state, static_cast<double*>(out), B);
+    return hipGetLastError();
+}
 }  // namespace vfik
 #endif  // VFIK_ONLY_NJ / VFIK_DISPATCH

@@ -20,10 +20,11 @@ class VfikError(RuntimeError):
 class IO(C.Structure):
     _fields_ = [("q", C.c_void_p), ("null_control", C.c_void_p), ("qdot_vf", C.c_void_p), ("qdot_null", C.c_void_p),
                 ("qdot_out", C.c_void_p), ("pose", C.c_void_p), ("pose_nt", C.c_void_p), ("v6", C.c_void_p),
-                ("qdist", C.c_void_p), ("status", C.c_void_p)]
+                ("qdist", C.c_void_p), ("status", C.c_void_p), ("goal_dist", C.c_void_p)]
 
 
-_OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n"}
+_OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n",
+               "goal_dist": 2}
 _lib = None
 
 
@@ -66,6 +67,8 @@ def load_library(path=None):
         "vfik_rollout": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
         "vfik_rollout_host": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
         "vfik_mix": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_track_error": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "vfik_track_reset": (C.c_int, [H]),
         "vfik_dev_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_dev_free": (C.c_int, [H, C.c_void_p]),
         "vfik_memcpy_h2d": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -287,6 +290,13 @@ class Engine:
 
     def d2h(self, arr, src):
         self._chk(self.lib.vfik_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src), arr.nbytes))
+
+    def track_error(self, pose_dev, v6_dev, out_dev):
+        """One step of the tracking-error estimator (vf:349-428) on device arrays."""
+        self._chk(self.lib.vfik_track_error(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(v6_dev)), C.c_void_p(_ptr(out_dev))))
+
+    def track_reset(self):
+        self._chk(self.lib.vfik_track_reset(self.h))
 
     def mix(self, cmds_dev, weights, out_dev):
         w = np.ascontiguousarray(weights, dtype=np.float64)

@@ -47,6 +47,46 @@ def _send(port, values, ints=()):
     port.write()
 
 
+class TrackingState:
+    """Majority vote over the last 20 samples of scripts/monitor_distance (monitor_distance:86-105,
+    173-219): 'on goal' / 'follow' / 'not follow' for the xyz and the rotational part, reported only
+    when the voted state changes."""
+    distanceXYZ_th, track_error_xyz_th = 0.02, 0.1        # monitor_distance:91-94
+    distanceOrient_th, track_error_rot_th = 1.0, 0.1      # monitor_distance:95-99 (degrees, radians)
+    size = 20                                             # monitor_distance:102
+    states = ("on goal", "follow", "not follow")
+
+    def __init__(self):
+        self.buffer = []
+        self.last = ["on goal", "on goal"]
+
+    @staticmethod
+    def _classify(dist, dist_th, err, err_th):
+        state = "on goal"
+        if dist > dist_th and err > err_th:
+            state = "not follow"
+        if dist > dist_th and err < err_th:
+            state = "follow"
+        if dist < dist_th:
+            state = "on goal"
+        return state
+
+    def update(self, dist_xyz, dist_rot_deg, err_xyz, err_rot):
+        """Returns the list of (kind, state) messages to emit this sample (usually empty)."""
+        self.buffer.append((self._classify(dist_xyz, self.distanceXYZ_th, err_xyz, self.track_error_xyz_th),
+                            self._classify(dist_rot_deg, self.distanceOrient_th, err_rot, self.track_error_rot_th)))
+        out = []
+        if len(self.buffer) > self.size:
+            self.buffer.pop(0)
+            for k, kind in enumerate(("xyz", "rot")):
+                col = [b[k] for b in self.buffer]
+                voted = max(self.states, key=col.count)
+                if voted != self.last[k]:
+                    self.last[k] = voted
+                    out.append((kind, voted))
+        return out
+
+
 class ControlCycleBatch:
     def __init__(self, chain, arm_bases, io_dtype=np.float64, max_fields=16, device=0, nullspace=True,
                  mixer=True, guard_time=2.0, params=None, open_ports=True, clock=time.time):
@@ -71,6 +111,8 @@ class ControlCycleBatch:
         self.ext_time = np.full((4, self.B), self.clock())
         self._ext_dirty = [False] * 4
         self.report_counter = 0  # vf:185,432-435
+        self.tracking = [TrackingState() for _ in range(self.B)]
+        self._track_bufs = None
         self.last = {}
         self.ports = []
         if open_ports:
@@ -95,6 +137,8 @@ class ControlCycleBatch:
                 "dbg_qin": mk(dbg + "/qin"), "qdist": mk(dbg + "/qdist"),
                 "encoders": mk(br + "/encoders"), "br_weight": mk(br + "/weight", True),
                 "current_weights": mk(br + "/current_weights"), "mixed": mk(br + "/mixed"),
+                "track_error": mk(vf + "/track_error"), "distOut": mk(base + "/dmonitor/distOut"),
+                "tracking_state": mk(base + "/dmonitor/tracking_state"),
             }
             for k in MIX_PORTS[2:]:
                 d[k] = mk(br + "/" + k)
@@ -209,7 +253,8 @@ class ControlCycleBatch:
         if not got_q.any():
             return got_q
         out = self.engine.step_host(self.q, null_control=self.control,
-                                    want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status"))
+                                    want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist"))
+        out["track_error"] = self._track_error(out)
         self.last = out
         self.report_counter += 1
         report = self.report_counter > 20  # vf:432-435
@@ -226,7 +271,38 @@ class ControlCycleBatch:
             _send(d["current_weights"], self.mix_w[a])       # bridge:627
             if report:
                 _send(d["vector_out"], out["v6"][a])         # vf:437-442
+            te = out["track_error"][a]
+            if te.any():                                      # from the 6th frame on (vf:354,418-428)
+                _send(d["track_error"], te[:7], ints=[int(te[7])])
+            if 1 in self.fields.sets[a]:                      # a goal exists: object 0 of /dmonitor/distOut
+                b = d["distOut"].prepare()
+                b.clear()
+                item = b.addList()
+                item.addDouble(0.0)                           # monitor_distance:165 sends the id as a double
+                item.addDouble(float(out["goal_dist"][a, 0]))
+                item.addDouble(float(out["goal_dist"][a, 1]))
+                d["distOut"].write()
+                for kind, state in self.tracking[a].update(out["goal_dist"][a, 0], out["goal_dist"][a, 1], te[0], te[1]):
+                    sb = d["tracking_state"].prepare()
+                    sb.clear()
+                    sb.addString(kind)
+                    sb.addString(state)
+                    d["tracking_state"].writeStrict()
         return got_q
+
+    def _track_error(self, out):
+        """The tracking-error estimator (vf:349-428) for the batch, on the device."""
+        e = self.engine
+        esz = e.io_dtype.itemsize
+        if self._track_bufs is None:
+            self._track_bufs = (e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * 6 * esz), e.dev_alloc(self.B * 8 * esz))
+        d_pose, d_v6, d_out = self._track_bufs
+        e.h2d(d_pose, out["pose"])
+        e.h2d(d_v6, out["v6"])
+        e.track_error(d_pose, d_v6, d_out)
+        res = np.zeros((self.B, 8), dtype=e.io_dtype)
+        e.d2h(res, d_out)
+        return res.astype(np.float64)
 
     def step_arrays(self, q, null_control=None, want=("qdot_out",)):
         """Array path: one cycle for the whole batch without any bottle."""
