@@ -32,6 +32,10 @@ __global__ void __launch_bounds__(256) k(double* out, unsigned long long* cyc, d
                 if (MODE == 8) x[c] = atan2(x[c], a);
                 if (MODE == 9) x[c] = pow(x[c], 2.5);
                 if (MODE == 10) { float f = (float)x[c]; f = __builtin_fmaf(f, 1.0000001f, 1e-9f); x[c] = f; }
+                if (MODE == 11) { float f; asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f) : "v"(x[c])); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x[c]) : "v"(f)); }
+                if (MODE == 12) x[c] = fmin(x[c], a);
+                if (MODE == 13) x[c] = x[c] > a ? b : x[c] + 1.0;
+                if (MODE == 14) { double r = __builtin_amdgcn_rsq(x[c]); x[c] = __builtin_fma(r, 0.5, 1.0); }
             }
         }
     }
@@ -61,7 +65,7 @@ int main() {
     hipMalloc(&cyc, 1024 * sizeof(unsigned long long));
 #define R(M, NAME) run<M, 1>(NAME, out, cyc); run<M, 2>(NAME, out, cyc); run<M, 4>(NAME, out, cyc); run<M, 8>(NAME, out, cyc);
     R(0, "fma_f64") R(1, "mul_f64") R(2, "add_f64") R(3, "rcp_f64") R(4, "rsq_f64") R(5, "div_f64") R(6, "sqrt_f64")
-    R(7, "sincos") R(8, "atan2") R(9, "pow") R(10, "fma_f32cv")
+    R(7, "sincos") R(8, "atan2") R(9, "pow") R(10, "fma_f32cv") R(11, "cvt32+cvt64") R(12, "min_f64") R(13, "cmp+cndmask+add") R(14, "rsq+fma")
     // s_memtime tick calibration: ticks per microsecond
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); hipLaunchKernelGGL((k<0, 1>), dim3(256), dim3(256), 0, 0, out, cyc, 1.5); hipEventRecord(e1);

@@ -514,8 +514,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             }
         }
     }
-    // values of the last evaluated cycle, for the outputs after the loop
-    double o_q[NJ], o_R[9], o_p[3], o_Rt[9], o_pt[3], o_v[3], o_w[3], o_qv[NJ], o_qn[NJ], o_qo[NJ], o_gd[2];
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
     double lv_r[NJ];
@@ -526,6 +524,14 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     }
     const int ncyc = ROLL ? a.n_cycles : 1;
     for (int cyc = 0; cyc < ncyc; ++cyc) {
+    // The LDS addresses are made opaque once per cycle for long chains: otherwise the compiler hoists the
+    // cycle-invariant reads (constants, goal, slots: ~200 doubles) out of the cycle loop and spills.
+    const KConst<NJ>* klc = kl;
+    int lanec = lane;
+    if (ROLL && NJ >= 10) {  // long chains have no registers to spare for cycle-invariant copies of the inputs
+        asm volatile("" : "+v"(klc));
+        asm volatile("" : "+v"(lanec));
+    }
     const bool first = !ROLL || cyc == 0;
     if (ROLL && !first && a.slots_used > PRE) {  // the rows hold the last chunk of the previous cycle
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -537,7 +543,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         // smoothly beyond (error ~ |angle| * 1e-21); NaN / Inf propagate and are flagged VFIK_ST_NAN.
         double ang[NJ];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) ang[i] = q[i] + kl->dh[i].off;
+        for (int i = 0; i < NJ; ++i) ang[i] = q[i] + klc->dh[i].off;
         sincos_fast_n<NJ>(ang, sn, cs);
     }
     if (first) {
@@ -548,8 +554,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R[3 * r + c] = kl->base[4 * r + c];
-        p[r] = kl->base[4 * r + 3];
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = klc->base[4 * r + c];
+        p[r] = klc->base[4 * r + 3];
     }
     // Jm[i] = column i of the 6 x n Jacobian (rows 0..2 linear, 3..5 angular); during the kinematics
     // it first holds the joint origin and axis.  The nullspace module later orthonormalises its ROWS in
@@ -560,10 +566,10 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         // joint i in DH form: Screw_z(angle, disp) Tx(a) Rx(alpha); ~33 flops, 9 constants from LDS
         Jm[i][3] = R[2]; Jm[i][4] = R[5]; Jm[i][5] = R[8];
         Jm[i][0] = p[0]; Jm[i][1] = p[1]; Jm[i][2] = p[2];
-        const double ci = PLAIN ? cs[i] : __builtin_fma(kl->dh[i].crev, cs[i], kl->dh[i].cprs);
-        const double si = PLAIN ? sn[i] : __builtin_fma(kl->dh[i].crev, sn[i], kl->dh[i].sprs);
-        const double di = PLAIN ? kl->dh[i].d : __builtin_fma(kl->dh[i].qd, q[i], kl->dh[i].d);
-        const double ai = kl->dh[i].a, ca = kl->dh[i].ca, sa = kl->dh[i].sa;
+        const double ci = PLAIN ? cs[i] : __builtin_fma(klc->dh[i].crev, cs[i], klc->dh[i].cprs);
+        const double si = PLAIN ? sn[i] : __builtin_fma(klc->dh[i].crev, sn[i], klc->dh[i].sprs);
+        const double di = PLAIN ? klc->dh[i].d : __builtin_fma(klc->dh[i].qd, q[i], klc->dh[i].d);
+        const double ai = klc->dh[i].a, ca = klc->dh[i].ca, sa = klc->dh[i].sa;
         double xn[3], ym[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
@@ -583,7 +589,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             if (first && i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
     }
     if (!PLAIN) {   // trailing z-screw of the last fixed transform
-        const double tc = kl->tail_c, ts = kl->tail_s, te = kl->tail_e;
+        const double tc = klc->tail_c, ts = klc->tail_s, te = klc->tail_e;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double x = R[3 * r], y = R[3 * r + 1];
@@ -624,7 +630,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double tl[12];
         if (a.tool_stride) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lane, tl + 4 * k);
+            for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lanec, tl + 4 * k);
         } else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
@@ -646,7 +652,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     {
         double gq[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lane, gq + 4 * k);
+        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lanec, gq + 4 * k);
         speed = gq[15];
         {   // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, speedScale]
             double GR[9], Gp[3];
@@ -679,8 +685,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
                     double s0[4], s1[4];
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lane, s0);
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lane, s1);
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
                     dx[m] = s0[0] - pt[0];
                     dy[m] = s0[1] - pt[1];
                     dz[m] = s0[2] - pt[2];
@@ -979,8 +985,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     if (a.flags & VFIK_F_MIXER) {
         double mw[8];
         if (a.mixw) {
-            read_quad<T>(region, Stage<T>::ROW_MIXW, lane, mw);
-            read_quad<T>(region, Stage<T>::ROW_MIXW + Q16, lane, mw + 4);
+            read_quad<T>(region, Stage<T>::ROW_MIXW, lanec, mw);
+            read_quad<T>(region, Stage<T>::ROW_MIXW + Q16, lanec, mw + 4);
         } else {
 #pragma unroll
             for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = kc->mix_w[k];
@@ -1015,13 +1021,60 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     for (int i = 0; i < NJ; ++i) nan = nan || (qo[i] != qo[i]);
     if (nan) status |= VFIK_ST_NAN;
 
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) { o_q[i] = q[i]; o_qv[i] = qv[i]; o_qn[i] = qn[i]; o_qo[i] = qo[i]; }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { o_R[k] = R[k]; o_Rt[k] = Rt[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { o_p[k] = p[k]; o_pt[k] = pt[k]; o_v[k] = v[k]; o_w[k] = w[k]; }
-    o_gd[0] = gdist[0]; o_gd[1] = gdist[1];
+    if (!ROLL || cyc == ncyc - 1) {  // the outputs are those of the last evaluated cycle
+        // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
+        if (a.qdot_out) {
+            T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
+    #pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)qo[i];
+        }
+        if (a.qdot_vf) {
+            T* o = static_cast<T*>(a.qdot_vf) + (long)arm * NJ;
+    #pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)qv[i];
+        }
+        if (a.qdot_null) {
+            T* o = static_cast<T*>(a.qdot_null) + (long)arm * NJ;
+    #pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)qn[i];
+        }
+        if (a.pose) {
+            T* o = static_cast<T*>(a.pose) + (long)arm * 16;
+    #pragma unroll
+            for (int r = 0; r < 3; ++r) {
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)Rt[3 * r + c];
+                o[4 * r + 3] = (T)pt[r];
+            }
+            o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
+        }
+        if (a.pose_nt) {
+            T* o = static_cast<T*>(a.pose_nt) + (long)arm * 16;
+    #pragma unroll
+            for (int r = 0; r < 3; ++r) {
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)R[3 * r + c];
+                o[4 * r + 3] = (T)p[r];
+            }
+            o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
+        }
+        if (a.v6) {
+            T* o = static_cast<T*>(a.v6) + (long)arm * 6;
+    #pragma unroll
+            for (int k = 0; k < 3; ++k) { o[k] = (T)v[k]; o[3 + k] = (T)w[k]; }
+        }
+        if (a.qdist) {
+            T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
+    #pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+
+        }
+        if (a.goal_dist) {  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
+            T* o = static_cast<T*>(a.goal_dist) + (long)arm * 2;
+            o[0] = (T)gdist[0];
+            o[1] = (T)(gdist[1] * 57.295779513082320877);
+        }
+    }
     if (ROLL) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
@@ -1039,63 +1092,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) o[i] = (T)q[i];
-    }
-    // the outputs below are those of the last evaluated cycle
-    double (&qo)[NJ] = o_qo; double (&qv)[NJ] = o_qv; double (&qn)[NJ] = o_qn; double (&qe)[NJ] = o_q;
-    double (&R)[9] = o_R; double (&Rt)[9] = o_Rt; double (&p)[3] = o_p; double (&pt)[3] = o_pt;
-    double (&v)[3] = o_v; double (&w)[3] = o_w;
-
-    // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
-    if (a.qdot_out) {
-        T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)qo[i];
-    }
-    if (a.qdot_vf) {
-        T* o = static_cast<T*>(a.qdot_vf) + (long)arm * NJ;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)qv[i];
-    }
-    if (a.qdot_null) {
-        T* o = static_cast<T*>(a.qdot_null) + (long)arm * NJ;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)qn[i];
-    }
-    if (a.pose) {
-        T* o = static_cast<T*>(a.pose) + (long)arm * 16;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)Rt[3 * r + c];
-            o[4 * r + 3] = (T)pt[r];
-        }
-        o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
-    }
-    if (a.pose_nt) {
-        T* o = static_cast<T*>(a.pose_nt) + (long)arm * 16;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)R[3 * r + c];
-            o[4 * r + 3] = (T)p[r];
-        }
-        o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
-    }
-    if (a.v6) {
-        T* o = static_cast<T*>(a.v6) + (long)arm * 6;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { o[k] = (T)v[k]; o[3 + k] = (T)w[k]; }
-    }
-    if (a.qdist) {
-        T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(qe[i] - kc->q_mid[i]) * kc->inv_half[i]);
-
-    }
-    if (a.goal_dist) {  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
-        T* o = static_cast<T*>(a.goal_dist) + (long)arm * 2;
-        o[0] = (T)o_gd[0];
-        o[1] = (T)(o_gd[1] * 57.295779513082320877);
     }
     if (a.status) a.status[arm] = status;
     STAMP(7);
