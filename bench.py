@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the real thing; gloo + --single-device rehearses the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
     args = ap.parse_args()
 
@@ -94,10 +97,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     robot, B, nobs, io_name, flags, bytes_per_cycle = WORKLOADS[args.workload]
     io_dtype = np.dtype(io_name)
@@ -109,6 +117,7 @@ def main():
     eng.set_fields(w["fields"], w["nfields"])
     tdt = torch.float32 if io_dtype == np.float32 else torch.float64
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the timing reductions run
     q = torch.from_numpy(w["q"].astype(io_dtype)).to(dev)
     qdot = torch.zeros(B, chain.n, dtype=tdt, device=dev)
     stream = torch.cuda.current_stream()
@@ -133,7 +142,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)  # same stream as the launches
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -155,7 +164,7 @@ def main():
         sync_all()
         r_ms = r0.elapsed_time(r1)
         if world > 1:
-            t = torch.tensor([r_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([r_ms], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             r_ms = float(t.item())
         rollout = {"cycles_per_launch": args.rollout, "launches": launches, "dt": 1e-3,
@@ -165,8 +174,9 @@ def main():
     gathered = None
     if args.gather and world > 1:
         # optional collation of the per-rank results (NOT part of the control path): one all_gather
-        parts = [torch.empty_like(qdot) for _ in range(world)]
-        dist.all_gather(parts, qdot)
+        src = qdot if args.dist_backend == "nccl" else qdot.cpu()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
         gathered = torch.cat(parts)
 
     if rank == 0:
