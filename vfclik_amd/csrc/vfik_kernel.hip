@@ -851,122 +851,187 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i)
 #pragma unroll
             for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
-        // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
-        // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
-        // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
-        int rank = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double n0 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) n0 += Jm[i][r] * Jm[i][r];
-#pragma unroll
-            for (int s = 0; s < r; ++s) {
-                double c = 0.0;
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) c += Jm[i][s] * Jm[i][r];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) Jm[i][r] -= c * Jm[i][s];
+        if constexpr (NJ <= 7) {
+            // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
+            // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
+            // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
+            int rank = 0;
+    #pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double n0 = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) n0 += Jm[i][r] * Jm[i][r];
+    #pragma unroll
+                for (int s = 0; s < r; ++s) {
+                    double c = 0.0;
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) c += Jm[i][s] * Jm[i][r];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) Jm[i][r] -= c * Jm[i][s];
+                }
+                double n1 = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) n1 += Jm[i][r] * Jm[i][r];
+                const bool keep = n1 > 1e-24 * n0 && n0 > 0.0;
+                double n1r, n1i;
+                sqrt_rsqrt(n1, n1r, n1i);
+                const double inv = keep ? n1i : 0.0;
+                rank += keep ? 1 : 0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) Jm[i][r] *= inv;
             }
-            double n1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) n1 += Jm[i][r] * Jm[i][r];
-            const bool keep = n1 > 1e-24 * n0 && n0 > 0.0;
-            double n1r, n1i;
-            sqrt_rsqrt(n1, n1r, n1i);
-            const double inv = keep ? n1i : 0.0;
-            rank += keep ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) Jm[i][r] *= inv;
-        }
-        const int nullity = NJ - rank;
-        if (nullity == 1) {
-            // the unique nullspace direction: normalised column of the projector with the largest diagonal
-            double best = -1.0;
-            int ib = 0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                double d = 1.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) d -= Jm[i][r] * Jm[i][r];
-                if (d > best) { best = d; ib = i; }
+            const int nullity = NJ - rank;
+            if (nullity == 1) {
+                // the unique nullspace direction: normalised column of the projector with the largest diagonal
+                double best = -1.0;
+                int ib = 0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    double d = 1.0;
+    #pragma unroll
+                    for (int r = 0; r < 6; ++r) d -= Jm[i][r] * Jm[i][r];
+                    if (d > best) { best = d; ib = i; }
+                }
+                double u[NJ];
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) u[i] = (i == ib) ? 1.0 : 0.0;
+    #pragma unroll
+                for (int pass = 0; pass < 2; ++pass)
+    #pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        double c = 0.0;
+    #pragma unroll
+                        for (int i = 0; i < NJ; ++i) c += Jm[i][r] * u[i];
+    #pragma unroll
+                        for (int i = 0; i < NJ; ++i) u[i] -= c * Jm[i][r];
+                    }
+                double nn = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
+                {
+                    double nr_, ni_;
+                    sqrt_rsqrt(nn, nr_, ni_);
+                    nn = ni_;
+                }
+                // raw sign as LAPACK's SVD leaves it (first non-negligible component negative; oracle + golden)
+                bool found = false;
+                double sg = 1.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    u[i] *= nn;
+                    if (!found && fabs(u[i]) > 1e-9) { found = true; sg = u[i] > 0.0 ? -1.0 : 1.0; }
+                }
+                // sign continuity against the previous cycle (nullspace:101-105)
+                if constexpr (!ROLL) {
+                    sig_r = a.sig[arm];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
+                }
+                int sig = sig_r;
+                double dm = 0.0, dp = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    u[i] *= sg;
+                    const double lv = lv_r[i];
+                    const double x = sig * u[i] - lv, y = sig * u[i] + lv;
+                    dm += x * x; dp += y * y;
+                }
+                if (sqrt(dm) > sqrt(dp)) sig = -sig;
+                sig_r = sig;
+                double c0 = 0.0;
+                if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    u[i] *= sig;
+                    lv_r[i] = u[i];
+                    qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
+                }
+                if constexpr (!ROLL) {
+                    a.sig[arm] = sig_r;
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
+                }
+            } else if (nullity >= 2) {
+                status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
             }
-            double u[NJ];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) u[i] = (i == ib) ? 1.0 : 0.0;
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
+            if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
+                double z[NJ];
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
+    #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     double c = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) c += Jm[i][r] * u[i];
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) u[i] -= c * Jm[i][r];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) c += Jm[i][r] * z[i];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) z[i] -= c * Jm[i][r];
                 }
-            double nn = 0.0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
-            {
-                double nr_, ni_;
-                sqrt_rsqrt(nn, nr_, ni_);
-                nn = ni_;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) qn[i] += z[i];
             }
-            // raw sign as LAPACK's SVD leaves it (first non-negligible component negative; oracle + golden)
-            bool found = false;
-            double sg = 1.0;
+        } else {
+            // n >= 8: the nullspace of a 6 x n Jacobian has dimension >= 2, so the reference's SVD basis is
+            // never unique and /control is never honoured; only the projector is needed (joint-limit task):
+            // (I - J^+ J) z = z - J^T (J J^T)^-1 J z with an LDL^T of the undamped Gram matrix.  A vanishing
+            // pivot (singular pose) drops that direction instead of dividing by it.
+            status |= VFIK_ST_NULL_AMBIGUOUS;
+            if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
+                double z[NJ], G[6][6], wv[6];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                u[i] *= nn;
-                if (!found && fabs(u[i]) > 1e-9) { found = true; sg = u[i] > 0.0 ? -1.0 : 1.0; }
+                for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    wv[r] = 0.0;
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        wv[r] = __builtin_fma(Jm[i][r], z[i], wv[r]);
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) G[r][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[r][c]);
+                    }
+                double gmax = G[0][0];
+#pragma unroll
+                for (int r = 1; r < 6; ++r) gmax = fmax(gmax, G[r][r]);
+                double gi[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    double v[6];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v[k] = G[j][k] * G[k][k];
+                    double dj = G[j][j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], v[k], dj);
+                    const bool okp = dj > 1e-12 * gmax;
+                    G[j][j] = okp ? dj : 0.0;
+                    gi[j] = okp ? rcp_nr(dj) : 0.0;
+#pragma unroll
+                    for (int k = 0; k < j; ++k)
+#pragma unroll
+                        for (int i = j + 1; i < 6; ++i) G[i][j] = __builtin_fma(-G[i][k], v[k], G[i][j]);
+#pragma unroll
+                    for (int i = j + 1; i < 6; ++i) G[i][j] *= gi[j];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int k = 0; k < i; ++k) wv[i] = __builtin_fma(-G[i][k], wv[k], wv[i]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wv[i] *= gi[i];
+#pragma unroll
+                for (int i = 5; i >= 0; --i)
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) wv[i] = __builtin_fma(-G[k][i], wv[k], wv[i]);
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i) z[i] = __builtin_fma(-Jm[i][r], wv[r], z[i]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) qn[i] += z[i];
             }
-            // sign continuity against the previous cycle (nullspace:101-105)
-            if constexpr (!ROLL) {
-                sig_r = a.sig[arm];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
-            }
-            int sig = sig_r;
-            double dm = 0.0, dp = 0.0;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                u[i] *= sg;
-                const double lv = lv_r[i];
-                const double x = sig * u[i] - lv, y = sig * u[i] + lv;
-                dm += x * x; dp += y * y;
-            }
-            if (sqrt(dm) > sqrt(dp)) sig = -sig;
-            sig_r = sig;
-            double c0 = 0.0;
-            if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                u[i] *= sig;
-                lv_r[i] = u[i];
-                qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
-            }
-            if constexpr (!ROLL) {
-                a.sig[arm] = sig_r;
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
-            }
-        } else if (nullity >= 2) {
-            status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
-        }
-        if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
-            double z[NJ];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double c = 0.0;
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) c += Jm[i][r] * z[i];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) z[i] -= c * Jm[i][r];
-            }
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) qn[i] += z[i];
         }
         // check_limits (nullspace:120-131) then gain (nullspace:183)
         bool stop = false;
