@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VFIK_ABI_VERSION 1
+#define VFIK_ABI_VERSION 2
 
 enum {
     VFIK_OK = 0,
@@ -44,6 +44,9 @@ enum {
 typedef struct vfik_handle vfik_handle;
 
 int vfik_abi_version(void);
+/* sizeof(vfik_field), sizeof(vfik_chain), sizeof(vfik_params), sizeof(vfik_io) as this library was built:
+ * a binding compares them with its own mirrors before the first call */
+void vfik_struct_sizes(size_t out[4]);
 const char* vfik_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never initialises a context) */
 int vfik_device_count(void);
@@ -112,6 +115,14 @@ typedef struct vfik_io {
     int32_t* status;          /* out [B]      VFIK_ST_* */
     void* goal_dist;          /* out [B][2]   xyz distance and rotation angle in DEGREES to the goal: the object-0
                                  entry of /dmonitor/distOut (monitor_distance:76-84,161-172) */
+    const void* q_ref;        /* in  [B][n]   /jpctrl/ref (joint_p_controller:113-118); NULL = no joint controller.
+                                 With VFIK_F_MIXER the controller's output kp*(clamp(ref,limits) - q)
+                                 (joint_p_controller:89-99,124-128) IS mixer channel 2 (/bridge/jointcmd,
+                                 joint_p_controller:78) and an external channel-2 command is not read */
+    const void* q_cmded;      /* in  [B][n]   the LWR's echo of its last commanded position (bridge:168-172);
+                                 NULL = velocity command.  With it qdot_out is the LWR command form
+                                 -q_cmded + q + qdot_lim (bridge:199-203) unless all mixer weights of the arm
+                                 are 0 ("direct_control", bridge:604).  vfik_step only */
 } vfik_io;
 
 /* One control cycle for the whole batch -- the loop bodies of vf:311-466, nullspace:162-184,

@@ -76,6 +76,8 @@ typedef struct vfik_params {
     double mix_w[VFIK_MIX_CHANNELS]; /* mixer weights, initial [1,1,0,0,0,0] (bridge:596) */
     uint32_t flags;
     uint32_t reserved;
+    double jp_kp;           /* joint P controller gain (joint_p_controller:55-56, config.jpctrl_kp; 1.5 in the source) */
+    double jp_delta;        /* joint P controller "reached" threshold, rad (joint_p_controller:57: 0.087) */
 } vfik_params;
 
 /* per-arm status bits written by vfik_step */
@@ -83,7 +85,9 @@ enum {
     VFIK_ST_NAN = 1 << 0,            /* a NaN reached a joint command (command_mixer.py:71-75 only prints) */
     VFIK_ST_LIMIT_STOP = 1 << 1,     /* nullspace look-ahead crossed a joint limit -> null command zeroed (nullspace:120-131) */
     VFIK_ST_NULL_AMBIGUOUS = 1 << 2, /* nullity != 1: the reference's SVD basis is not unique; /control ignored */
-    VFIK_ST_LIMITED = 1 << 3         /* bridge limiter scaled the command (bridge:190-191) */
+    VFIK_ST_LIMITED = 1 << 3,        /* bridge limiter scaled the command (bridge:190-191) */
+    VFIK_ST_JOINT_AT_GOAL = 1 << 4   /* /jpctrl/at_goal (joint_p_controller:134-146): every ref_i - q_i < jp_delta
+                                        (signed, as the reference compares it); only with io->q_ref */
 };
 
 #ifdef __cplusplus

@@ -84,6 +84,33 @@ def mix(cmd, w):
     return out
 
 
+def joint_p(ref, q, lo, hi, kp, delta):
+    """(B,n) references and angles -> (kp*(clamp(ref)-q), at_goal flags)."""
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    B, n = q.shape
+    out = np.zeros((B, n))
+    flags = np.zeros(B, dtype=np.int32)
+    fn = lib().vfo_joint_p
+    fn.restype = C.c_int
+    for b in range(B):
+        flags[b] = fn(_p(ref[b]), _p(q[b]), _p(lo), _p(hi), C.c_int(n), C.c_double(kp), C.c_double(delta), _p(out[b]))
+    return out, flags
+
+
+def lwr_cmd(qdot_lim, q, q_cmded, direct):
+    qdot_lim = np.ascontiguousarray(qdot_lim, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    q_cmded = np.ascontiguousarray(q_cmded, dtype=np.float64)
+    B, n = q.shape
+    out = np.zeros((B, n))
+    for b in range(B):
+        lib().vfo_lwr_cmd(_p(qdot_lim[b]), _p(q[b]), _p(q_cmded[b]), C.c_int(n), C.c_int(int(direct[b])), _p(out[b]))
+    return out
+
+
 def restrict(J):
     J = np.ascontiguousarray(J, dtype=np.float64)
     n = J.shape[1]

@@ -396,6 +396,33 @@ def limiter(qdot, max_vel):  # LWR_Bridge.set_vel, bridge:188-195
     return [v * ratio for v in qdot], lead > max_vel
 
 
+def lwr_command(qdot_lim, last_q, last_qcmded, direct_control):  # LWR_Bridge.set_vel, bridge:198-203
+    cmd = len(qdot_lim) * [0.0]
+    for i in range(len(qdot_lim)):
+        if direct_control:
+            cmd[i] = qdot_lim[i]
+        else:
+            cmd[i] = -last_qcmded[i] + last_q[i] + qdot_lim[i]
+    return cmd
+
+
+def joint_p_controller(ref, q, limits, kp, delta):
+    """scripts/joint_p_controller: check_limits (:89-99), outqdot = (ref - q) * kp (:127-128) and the
+    /at_goal flag (:134-138; the error is compared signed, as written there)."""
+    ref_out = list(ref)
+    for i in range(len(limits)):
+        if ref[i] < limits[i][0]:
+            ref_out[i] = limits[i][0]
+        elif ref[i] > limits[i][1]:
+            ref_out[i] = limits[i][1]
+    error = np.asarray(ref_out, dtype=float) - np.asarray(q, dtype=float)
+    outqdot = error * kp
+    all_reached = True
+    for x in error:
+        all_reached = all_reached and bool(x < delta)
+    return outqdot.tolist(), all_reached
+
+
 # ---------------------------------------------------------------------------------------------
 # one control cycle of one arm, in the order of the reference processes
 # ---------------------------------------------------------------------------------------------

@@ -423,6 +423,26 @@ int vfo_limiter(double* qdot, int n, double max_vel) {
     return 0;
 }
 
+/* scripts/joint_p_controller: check_limits (:89-99), error * kp (:127-128), at_goal (:134-138) */
+int vfo_joint_p(const double* ref, const double* q, const double* lo, const double* hi, int n,
+                double kp, double delta, double* out) {
+    int reached = 1;
+    for (int i = 0; i < n; ++i) {
+        double r = ref[i];
+        if (r < lo[i]) r = lo[i];
+        else if (r > hi[i]) r = hi[i];
+        double err = r - q[i];
+        out[i] = err * kp;
+        if (!(err < delta)) reached = 0; /* signed comparison, as the reference writes it */
+    }
+    return reached;
+}
+
+/* LWR_Bridge.set_vel, the command form (bridge:199-203) */
+void vfo_lwr_cmd(const double* qdot_lim, const double* q, const double* q_cmded, int n, int direct, double* cmd) {
+    for (int i = 0; i < n; ++i) cmd[i] = direct ? qdot_lim[i] : -q_cmded[i] + q[i] + qdot_lim[i];
+}
+
 void vfo_state_init(vfo_state* s, int n) {
     memset(s->lastvec, 0, sizeof s->lastvec); /* nullspace:92 */
     for (int i = 0; i < MAXJ; ++i) s->sig[i] = 1; /* nullspace:91 */

@@ -50,6 +50,12 @@ void vfo_dist_to_center(const double* q, const double* lo, const double* hi, int
 void vfo_mix(const double* cmd /*K x n*/, const double* w, int K, int n, double* out);
 /* bridge limiter (bridge:188-195); returns 1 when scaled */
 int vfo_limiter(double* qdot, int n, double max_vel);
+/* joint P controller (joint_p_controller:89-99,124-128,134-138): out = kp * (clamp(ref, lo, hi) - q);
+ * returns 1 when every signed error is below delta (the /at_goal flag) */
+int vfo_joint_p(const double* ref, const double* q, const double* lo, const double* hi, int n,
+                double kp, double delta, double* out);
+/* LWR command form (bridge:199-203): cmd = qdot_lim when direct_control, else -q_cmded + q + qdot_lim */
+void vfo_lwr_cmd(const double* qdot_lim, const double* q, const double* q_cmded, int n, int direct, double* cmd);
 
 /* per-arm persistent state of the nullspace module (nullspace:91-92) */
 typedef struct vfo_state {

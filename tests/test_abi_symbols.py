@@ -31,7 +31,11 @@ def test_struct_sizes_match_header(lib):
     from vfclik_amd import _abi
     assert ctypes.sizeof(_abi.Field) == 152 == _abi.FIELD_DTYPE.itemsize
     assert ctypes.sizeof(_abi.Chain) == 4 + 4 * 16 + 4 + 8 * 12 * 17 + 8 * 16 * 2  # n, jtype, pad, B, limits
-    assert ctypes.sizeof(_abi.Params) == 8 * 7 + 8 * 6 + 8 * 16 + 8 * 6 + 8
+    assert ctypes.sizeof(_abi.Params) == 8 * 7 + 8 * 6 + 8 * 16 + 8 * 6 + 8 + 16
+    from vfclik_amd import engine
+    sizes = (ctypes.c_size_t * 4)()
+    lib.vfik_struct_sizes(sizes)  # what the C compiler made of include/vfik_types.h
+    assert list(sizes) == [ctypes.sizeof(_abi.Field), ctypes.sizeof(_abi.Chain), ctypes.sizeof(_abi.Params), ctypes.sizeof(engine.IO)]
 
 
 def test_supported_joints(lib):

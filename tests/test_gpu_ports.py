@@ -190,3 +190,57 @@ def test_goto_frame_blocks_until_the_monitor_reports_arrival(net):
     assert diff[0] < 0.005 and diff[1] < 0.05 and state["cycles"] > 20
     cc.close()
     feeder.close()
+
+
+def test_joint_controller_through_ports(net):
+    """HandleJController.set_ref_js -> /jpctrl/ref -> fused joint P controller -> /bridge/mixed and
+    /jpctrl/at_goal (handlers.py:544-576, joint_p_controller:113-146)."""
+    yarp = net
+    from oracle import oracle_c
+    from vfclik_amd import robots
+    from vfclik_amd.handlers import HandleArmNew, HandleJController
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    bases = ["/0/lwr/right", "/0/lwr/left"]
+    cc = ControlCycleBatch(chain, bases, io_dtype=np.float64)
+    arm = HandleArmNew(arm="/right")
+    jctrl = HandleJController(bases[0])
+    enc = [_open(yarp, "/sim%d/encoders" % k) for k in range(2)]
+    mixed, at_goal = _open(yarp, "/probe/mixed"), _open(yarp, "/probe/at_goal")
+    mixed_l = _open(yarp, "/probe/mixed_l")
+    yarp.Network.connect("/sim0/encoders", bases[0] + "/vectorField/qIn")
+    yarp.Network.connect("/sim1/encoders", bases[1] + "/vectorField/qIn")
+    yarp.Network.connect(bases[0] + "/bridge/mixed", "/probe/mixed")
+    yarp.Network.connect(bases[1] + "/bridge/mixed", "/probe/mixed_l")
+    yarp.Network.connect(bases[0] + "/jpctrl/at_goal", "/probe/at_goal")
+    rng = np.random.default_rng(8)
+    q = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (2, 7))
+    ref = q[0] + rng.uniform(-0.5, 0.5, 7)
+    ref[3] = chain.q_hi[3] + 0.4  # beyond the limit: clamped (joint_p_controller:89-99)
+    arm.set_joint_control()       # mixer weights [0, 0, 1, 0]
+    jctrl.set_ref_js(ref)
+    for k in range(2):
+        _send(enc[k], q[k])
+    assert cc.cycle().all()
+    want, flag = oracle_c.joint_p(ref[None], q[:1], chain.q_lo, chain.q_hi, cc.params.jp_kp, cc.params.jp_delta)
+    assert np.abs(_read(mixed) - want[0]).max() < 1e-12
+    b = at_goal.read(False)
+    assert b is not None and b.get(0).asInt() == int(flag[0]) == 0
+    # the other arm has no reference: its joint channel commands nothing and nothing is reported
+    got_l = _read(mixed_l)
+    assert got_l is not None and np.isfinite(got_l).all()
+    # drive the arm to the reference through the ports: at_goal turns 1
+    qa = q[0].copy()
+    for _ in range(400):
+        _send(enc[0], qa)
+        cc.cycle()
+        qa = qa + 0.01 * _read(mixed)
+    b = None
+    while True:
+        nb = at_goal.read(False)
+        if nb is None:
+            break
+        b = nb
+    assert b.get(0).asInt() == 1
+    assert np.abs(qa - np.clip(ref, chain.q_lo, chain.q_hi)).max() < 0.02
+    cc.close()

@@ -17,7 +17,7 @@ FIELD_NULL, FIELD_ATTRACTOR, FIELD_REPELLER, FIELD_HEMISPHERE, FIELD_FUNNEL = 0,
 FIELD_NPARAMS = {FIELD_NULL: 0, FIELD_ATTRACTOR: 17, FIELD_REPELLER: 6, FIELD_HEMISPHERE: 8, FIELD_FUNNEL: 10}
 
 F_NULLSPACE, F_JOINT_LIMIT_TASK, F_MIXER, F_LIMITER = 1, 2, 4, 8
-ST_NAN, ST_LIMIT_STOP, ST_NULL_AMBIGUOUS, ST_LIMITED = 1, 2, 4, 8
+ST_NAN, ST_LIMIT_STOP, ST_NULL_AMBIGUOUS, ST_LIMITED, ST_JOINT_AT_GOAL = 1, 2, 4, 8, 16
 
 #: numpy view of ``struct vfik_field`` (152 bytes)
 FIELD_DTYPE = np.dtype([("id", "<i4"), ("type", "<i4"), ("force", "<f8"), ("p", "<f8", (MAX_PARAMS,))])
@@ -38,7 +38,8 @@ class Params(C.Structure):
     _fields_ = [("speed_scale", C.c_double), ("lambda_", C.c_double), ("rot_slowdown", C.c_double),
                 ("null_gain", C.c_double), ("lookahead", C.c_double), ("jl_gain", C.c_double),
                 ("max_vel", C.c_double), ("wy", C.c_double * 6), ("wq", C.c_double * MAX_JOINTS),
-                ("mix_w", C.c_double * MIX_CHANNELS), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("mix_w", C.c_double * MIX_CHANNELS), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("jp_kp", C.c_double), ("jp_delta", C.c_double)]
 
 
 def default_params(**kw):
@@ -47,6 +48,7 @@ def default_params(**kw):
     p = Params()
     p.speed_scale, p.lambda_, p.rot_slowdown = 1.0, 0.1, 0.3
     p.null_gain, p.lookahead, p.jl_gain, p.max_vel = 0.5, 0.3, 0.5, 1.0
+    p.jp_kp, p.jp_delta = 1.5, 0.087  # joint_p_controller:55,57
     for i in range(6):
         p.wy[i] = 1.0
     for i in range(MAX_JOINTS):

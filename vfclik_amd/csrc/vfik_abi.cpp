@@ -159,6 +159,8 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.null_control = io->null_control;
     a.ext = h->d_ext;
     a.mixw = h->d_mixw_arm;
+    a.q_ref = io->q_ref;
+    a.q_cmded = io->q_cmded;
     a.lastvec = h->d_lastvec;
     a.sig = h->d_sig;
     a.qdot_vf = io->qdot_vf;
@@ -217,6 +219,10 @@ extern "C" {
 
 int vfik_abi_version(void) { return VFIK_ABI_VERSION; }
 
+void vfik_struct_sizes(size_t out[4]) {
+    out[0] = sizeof(vfik_field); out[1] = sizeof(vfik_chain); out[2] = sizeof(vfik_params); out[3] = sizeof(vfik_io);
+}
+
 const char* vfik_last_error(void) { return g_err.c_str(); }
 
 int vfik_device_count(void) {
@@ -267,7 +273,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (vfik_reset_state(h) != VFIK_OK) return bail("reset_state");
     vfik_params p{};
     p.speed_scale = 1.0; p.lambda = 0.1; p.rot_slowdown = 0.3; p.null_gain = 0.5; p.lookahead = 0.3;
-    p.jl_gain = 0.5; p.max_vel = 1.0;
+    p.jl_gain = 0.5; p.max_vel = 1.0; p.jp_kp = 1.5; p.jp_delta = 0.087;
     for (double& w : p.wy) w = 1.0;
     for (double& w : p.wq) w = 1.0;
     p.mix_w[0] = p.mix_w[1] = 1.0;
@@ -496,6 +502,7 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     if (check_handle(h)) return VFIK_E_ARG;
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
+    if (n_cycles > 0 && io->q_cmded) return fail(VFIK_E_ARG, "io->q_cmded (LWR position command form) is for vfik_step only");
     HIP_TRY(hipSetDevice(h->device));
     vfik::KArgs a;
     fill_kargs(h, io, a);
@@ -528,8 +535,9 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     HIP_TRY(hipSetDevice(h->device));
     const size_t B = h->B, n = h->n, e = h->esz;
-    const void* hin[2] = {io->q, io->null_control};
-    const size_t bin[2] = {B * n * e, B * VFIK_NULL_CONTROLS * e};
+    const void* hin[4] = {io->q, io->null_control, io->q_ref, io->q_cmded};
+    const size_t bin[4] = {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e};
+    static const int in_slot[4] = {0, 1, 12, 13};
     void* hout[10] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host, io->goal_dist};
     const size_t bout[10] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e};
     auto need = [&](int i, size_t bytes) -> void* {
@@ -542,10 +550,10 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
         }
         return s.p;
     };
-    void* din[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; ++i)
+    void* din[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i)
         if (hin[i]) {
-            din[i] = need(i, bin[i]);
+            din[i] = need(in_slot[i], bin[i]);
             if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
             HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->stream));
         }
@@ -555,7 +563,7 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
         if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
     }
     vfik_io d{};
-    d.q = din[0]; d.null_control = din[1];
+    d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
     d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
     d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[9];
     const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);

@@ -55,6 +55,7 @@ struct KConst {
     double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
     double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
     double cos_slow;  // cos(rot_slow): rotation angles with a smaller cosine need no atan2 (scalar = 1)
+    double jp_kp, jp_delta;  // joint P controller (joint_p_controller:55-57)
     unsigned prismatic_mask;
     unsigned pad0;
     static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
@@ -78,6 +79,8 @@ struct KArgs {
     const void* null_control;
     const void* ext;
     const void* mixw;  // per-arm mixer weights, 2 quad planes, or NULL (KConst::mix_w for every arm)
+    const void* q_ref;    // [B][n] joint P controller reference (mixer channel 2), or NULL
+    const void* q_cmded;  // [B][n] LWR echo of the commanded position (bridge:199-203 command form), or NULL
     double* lastvec;
     int* sig;
     void* qdot_vf;

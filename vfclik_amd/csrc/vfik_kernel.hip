@@ -1047,6 +1047,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
     double qo[NJ];
+    bool direct = false;
     if (a.flags & VFIK_F_MIXER) {
         double mw[8];
         if (a.mixw) {
@@ -1058,14 +1059,32 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mac_unfused(0.0, qv[i], mw[0]), qn[i], mw[1]);
+        if (a.q_ref) {  // joint P controller -> /bridge/jointcmd = channel 2 (joint_p_controller:78,89-99,124-128)
+            const T* rf = static_cast<const T*>(a.q_ref) + (long)arm * NJ;
+            bool reached = true;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const double rv = (double)rf[i];  // check_limits, joint_p_controller:89-99
+                const double ref = rv < kc->q_lo[i] ? kc->q_lo[i] : (rv > kc->q_hi[i] ? kc->q_hi[i] : rv);
+                const double err = ref - q[i];
+                reached = reached && err < kc->jp_delta;  // signed, as joint_p_controller:135 compares it
+                qo[i] = mac_unfused(qo[i], err * kc->jp_kp, mw[2]);
+            }
+            if (reached) status |= VFIK_ST_JOINT_AT_GOAL;
+        }
         if (a.ext) {
             const T* e = static_cast<const T*>(a.ext);
 #pragma unroll
-            for (int ch = 0; ch < VFIK_MIX_CHANNELS - 2; ++ch)
+            for (int ch = 0; ch < VFIK_MIX_CHANNELS - 2; ++ch) {
+                if (ch == 0 && a.q_ref) continue;
 #pragma unroll
                 for (int i = 0; i < NJ; ++i)
                     qo[i] = mac_unfused(qo[i], (double)e[((long)ch * Bs + arm) * NJ + i], mw[2 + ch]);
+            }
         }
+        direct = true;  // bridge:604: no controller has a weight -> the velocity goes out as it is
+#pragma unroll
+        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) direct = direct && mw[k] == 0.0;
     } else {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) qo[i] = qv[i];
@@ -1090,8 +1109,14 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
         if (a.qdot_out) {
             T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
+            if (!ROLL && a.q_cmded && !direct) {  // LWR command form (bridge:199-203): -last_qcmded + last_q + qdot_lim
+                const T* qc = static_cast<const T*>(a.q_cmded) + (long)arm * NJ;
     #pragma unroll
-            for (int i = 0; i < NJ; ++i) o[i] = (T)qo[i];
+                for (int i = 0; i < NJ; ++i) o[i] = (T)((-(double)qc[i] + q[i]) + qo[i]);
+            } else {
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) o[i] = (T)qo[i];
+            }
         }
         if (a.qdot_vf) {
             T* o = static_cast<T*>(a.qdot_vf) + (long)arm * NJ;
@@ -1384,6 +1409,8 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.null_gain = p.null_gain;
     c.lookahead = p.lookahead;
     c.max_vel = p.max_vel;
+    c.jp_kp = p.jp_kp;
+    c.jp_delta = p.jp_delta;
     // PLAIN variant of the kernel: revolute joints only, no trailing screw, identity tool, unit weights
     bool pl = c.prismatic_mask == 0 && c.tail_c == 1.0 && c.tail_s == 0.0 && c.tail_e == 0.0;
     static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};

@@ -20,7 +20,8 @@ class VfikError(RuntimeError):
 class IO(C.Structure):
     _fields_ = [("q", C.c_void_p), ("null_control", C.c_void_p), ("qdot_vf", C.c_void_p), ("qdot_null", C.c_void_p),
                 ("qdot_out", C.c_void_p), ("pose", C.c_void_p), ("pose_nt", C.c_void_p), ("v6", C.c_void_p),
-                ("qdist", C.c_void_p), ("status", C.c_void_p), ("goal_dist", C.c_void_p)]
+                ("qdist", C.c_void_p), ("status", C.c_void_p), ("goal_dist", C.c_void_p),
+                ("q_ref", C.c_void_p), ("q_cmded", C.c_void_p)]
 
 
 _OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n",
@@ -47,6 +48,7 @@ def load_library(path=None):
     H = C.c_void_p
     protos = {
         "vfik_abi_version": (C.c_int, []),
+        "vfik_struct_sizes": (None, [C.POINTER(C.c_size_t)]),
         "vfik_last_error": (C.c_char_p, []),
         "vfik_device_count": (C.c_int, []),
         "vfik_supported_joints": (C.c_uint32, []),
@@ -81,8 +83,13 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
         fn.restype = res
         fn.argtypes = args
-    if lib.vfik_abi_version() != 1:
+    if lib.vfik_abi_version() != 2:
         raise VfikError("ABI version mismatch")
+    sizes = (C.c_size_t * 4)()
+    lib.vfik_struct_sizes(sizes)
+    mine = [C.sizeof(_abi.Field), C.sizeof(_abi.Chain), C.sizeof(_abi.Params), C.sizeof(IO)]
+    if list(sizes) != mine:
+        raise VfikError("struct layout mismatch: library %s, Python mirrors %s" % (list(sizes), mine))
     if path == _abi.HIP_LIB_PATH or _lib is None:
         _lib = lib
     return lib
@@ -204,14 +211,22 @@ class Engine:
         d = _OUT_SHAPES[key]
         return (self.batch, self.n if d == "n" else d)
 
-    def step_host(self, q, null_control=None, want=("qdot_out",)):
-        """Host arrays in, host arrays out (copies + sync inside the library)."""
+    def step_host(self, q, null_control=None, want=("qdot_out",), q_ref=None, q_cmded=None):
+        """Host arrays in, host arrays out (copies + sync inside the library).  q_ref: /jpctrl/ref of the
+        joint P controller (mixer channel 2); q_cmded: the LWR's commanded-position echo (bridge:199-203)."""
         q = np.ascontiguousarray(q, dtype=self.io_dtype)
         if q.shape != (self.batch, self.n):
             raise ValueError("q must be (%d, %d), got %s" % (self.batch, self.n, q.shape))
         io = IO()
         io.q = q.ctypes.data
         keep = [q]
+        for name, arr in (("q_ref", q_ref), ("q_cmded", q_cmded)):
+            if arr is not None:
+                a = np.ascontiguousarray(arr, dtype=self.io_dtype)
+                if a.shape != (self.batch, self.n):
+                    raise ValueError("%s must be (%d, %d), got %s" % (name, self.batch, self.n, a.shape))
+                setattr(io, name, a.ctypes.data)
+                keep.append(a)
         if null_control is not None:
             nc = np.ascontiguousarray(null_control, dtype=self.io_dtype)
             if nc.shape != (self.batch, _abi.NULL_CONTROLS):
@@ -228,7 +243,7 @@ class Engine:
         self._chk(self.lib.vfik_step_host(self.h, C.byref(io)))
         return out
 
-    def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",)):
+    def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",), q_ref=None):
         """n_cycles control cycles in one launch with q integrated on the device.
         Returns the outputs of the last cycle plus ``q`` = joint angles after it."""
         q = np.ascontiguousarray(q, dtype=self.io_dtype)
@@ -237,6 +252,12 @@ class Engine:
         io = IO()
         io.q = q.ctypes.data
         keep = [q]
+        if q_ref is not None:
+            a = np.ascontiguousarray(q_ref, dtype=self.io_dtype)
+            if a.shape != (self.batch, self.n):
+                raise ValueError("q_ref must be (%d, %d), got %s" % (self.batch, self.n, a.shape))
+            io.q_ref = a.ctypes.data
+            keep.append(a)
         if null_control is not None:
             nc = np.ascontiguousarray(null_control, dtype=self.io_dtype)
             io.null_control = nc.ctypes.data
@@ -253,11 +274,13 @@ class Engine:
         """Asynchronous device-pointer form of :meth:`rollout_host`."""
         self._chk(self.lib.vfik_rollout(self.h, C.byref(io), int(n_cycles), float(dt), 1 if clamp else 0, C.c_void_p(_ptr(q_out))))
 
-    def make_io(self, q, null_control=None, **outs):
+    def make_io(self, q, null_control=None, q_ref=None, q_cmded=None, **outs):
         """IO block from device pointers (torch tensors on this device, or raw addresses)."""
         io = IO()
         io.q = _ptr(q)
         io.null_control = _ptr(null_control)
+        io.q_ref = _ptr(q_ref)
+        io.q_cmded = _ptr(q_cmded)
         for k, v in outs.items():
             setattr(io, k, _ptr(v))
         return io

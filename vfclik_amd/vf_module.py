@@ -110,6 +110,8 @@ class ControlCycleBatch:
         self.ext = np.zeros((4, self.B, self.n))
         self.ext_time = np.full((4, self.B), self.clock())
         self._ext_dirty = [False] * 4
+        self.q_ref = np.zeros((self.B, self.n))          # /jpctrl/ref (joint_p_controller:113-118)
+        self.has_ref = np.zeros(self.B, dtype=bool)      # no reference yet: the controller commands nothing
         self.report_counter = 0  # vf:185,432-435
         self.tracking = [TrackingState() for _ in range(self.B)]
         self._track_bufs = None
@@ -139,6 +141,7 @@ class ControlCycleBatch:
                 "current_weights": mk(br + "/current_weights"), "mixed": mk(br + "/mixed"),
                 "track_error": mk(vf + "/track_error"), "distOut": mk(base + "/dmonitor/distOut"),
                 "tracking_state": mk(base + "/dmonitor/tracking_state"),
+                "jp_ref": mk(base + "/jpctrl/ref"), "jp_at_goal": mk(base + "/jpctrl/at_goal"),
             }
             for k in MIX_PORTS[2:]:
                 d[k] = mk(br + "/" + k)
@@ -200,6 +203,10 @@ class ControlCycleBatch:
                         self._ext_dirty[ch] = True
                 elif b:
                     log.warning("arm %d: wrong length for data bottle on %s", a, name)
+            b = d["jp_ref"].read(False)  # joint_p_controller:113-118
+            if b and b.size() == self.n:
+                self.q_ref[a] = _bottle_doubles(b)
+                self.has_ref[a] = True
             b = d["qIn"].read(False)  # vf:312-313
             d["ns_qin"].read(False)
             d["dbg_qin"].read(False)
@@ -252,7 +259,10 @@ class ControlCycleBatch:
         self._push_state()
         if not got_q.any():
             return got_q
-        out = self.engine.step_host(self.q, null_control=self.control,
+        # the joint P controller feeds /bridge/jointcmd (joint_p_controller:78): once any arm has a
+        # reference the fused controller owns mixer channel 2; arms without one get ref = q (zero command)
+        ref = np.where(self.has_ref[:, None], self.q_ref, self.q) if self.has_ref.any() else None
+        out = self.engine.step_host(self.q, null_control=self.control, q_ref=ref,
                                     want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist"))
         out["track_error"] = self._track_error(out)
         self.last = out
@@ -269,6 +279,8 @@ class ControlCycleBatch:
             _send(d["qdist"], 100.0 * out["qdist"][a])       # debug_jointlimits:68-73
             _send(d["mixed"], out["qdot_out"][a])            # what bridge.set_vel receives (bridge:626)
             _send(d["current_weights"], self.mix_w[a])       # bridge:627
+            if self.has_ref[a]:                               # joint_p_controller:139-146
+                _send(d["jp_at_goal"], [], ints=[1 if out["status"][a] & _abi.ST_JOINT_AT_GOAL else 0])
             if report:
                 _send(d["vector_out"], out["v6"][a])         # vf:437-442
             te = out["track_error"][a]
