@@ -152,6 +152,13 @@ int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt
 int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out);
 int vfik_track_reset(vfik_handle* h);
 
+/* Distance monitor of scripts/monitor_distance (monitor_distance:76-84,148-167) for the batch: device
+ * pose[B][16] (what vfik_step wrote to io->pose), device frames[B][max_objects][16] (the object frames of
+ * /dmonitor/objectsIn, object_feeder:215-227,306-315; unused slots may hold anything finite), device
+ * out[B][max_objects][2] = xyz distance, rotation angle in DEGREES -- one /dmonitor/distOut entry each
+ * (monitor_distance:161-167).  Asynchronous on the handle's stream. */
+int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, int max_objects, void* out);
+
 /* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
  * host weights[K], device out[B][n].  Bit-exact with the reference's left-to-right sum. */
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out);

@@ -544,6 +544,17 @@ class TrackingError:
         return np.array([vel_diff_angle, rot_diff_angle, ev, er, cv, cr, ext_int_diff, float(ext_int_diff < tracking_th)])
 
 
+def object_distances(pose16, objects):
+    """scripts/monitor_distance:148-167: for every object of the dictionary (id -> 16-list), in dictionary
+    order, [id, xyz distance, orientLength in degrees] -- the entries of one /dmonitor/distOut bottle."""
+    F = listToKdlFrame(pose16)
+    out = []
+    for i in objects:
+        G = listToKdlFrame(objects[i])
+        out.append([i, norm(F.p - G.p), 180.0 * norm(rot_log(F.M, G.M)) / math.pi])
+    return out
+
+
 def goal_distance(pose16, goal16):
     """The object-0 entry of /dmonitor/distOut: xyz distance and orientLength in degrees
     (scripts/monitor_distance:76-84,161-167)."""

@@ -52,3 +52,43 @@ def test_goal_distance_and_tracking_error():
     for p in (d_pose, d_v6, d_out):
         eng.dev_free(p)
     eng.close()
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-9), (np.float32, 2e-2)])
+def test_object_distances_match_the_monitor(dt, tol):
+    """vfik_object_distances vs the restatement of monitor_distance:148-167 (xyz distance, rotation angle in
+    degrees) for random object frames, plus the corner cases: same orientation (0), half turn (180)."""
+    import __graft_entry__ as g
+    g.build()
+    from oracle import vfik_numpy as vn
+    from vfclik_amd import engine, robots
+    chain = robots.lwr()
+    B, O = 130, 5
+    rng = np.random.default_rng(12)
+    pose = chain.fk(rng.uniform(chain.q_lo, chain.q_hi, (B, 7))).reshape(B, 16).astype(dt)
+    frames = chain.fk(rng.uniform(chain.q_lo, chain.q_hi, (B * O, 7))).reshape(B, O, 16).astype(dt)
+    frames[:, 0] = pose                                  # object on the tool: distance 0, angle 0
+    frames[:, 1] = pose
+    frames[:, 1, [0, 1, 4, 5, 8, 9]] *= -1               # R_cur * Rz(pi): a half turn, columns x and y negated
+    frames[:, 1, 3] += 0.25                              # and 25 cm away in x
+    eng = engine.Engine(chain, B, io_dtype=dt, max_slots=2)
+    esz = np.dtype(dt).itemsize
+    d_pose, d_fr, d_out = eng.dev_alloc(B * 16 * esz), eng.dev_alloc(B * O * 16 * esz), eng.dev_alloc(B * O * 2 * esz)
+    eng.h2d(d_pose, pose)
+    eng.h2d(d_fr, frames)
+    eng.object_distances(d_pose, d_fr, O, d_out)
+    got = np.zeros((B, O, 2), dtype=dt)
+    eng.d2h(got, d_out)
+    for b in range(B):
+        ref = vn.object_distances(pose[b].astype(np.float64), {k: frames[b, k].astype(np.float64) for k in range(O)})
+        for k, (oid, dxyz, dang) in enumerate(ref):
+            assert oid == k
+            assert abs(got[b, k, 0] - dxyz) < (1e-12 if dt == np.float64 else 1e-6)
+            assert abs(got[b, k, 1] - dang) < tol, (b, k, got[b, k, 1], dang)
+    assert np.abs(got[:, 0]).max() < (1e-6 if dt == np.float64 else 0.1)
+    assert np.abs(got[:, 1, 0] - 0.25).max() < 1e-6 and np.abs(got[:, 1, 1] - 180.0).max() < (1e-5 if dt == np.float64 else 0.1)
+    with pytest.raises(engine.VfikError):
+        eng.object_distances(d_pose, d_fr, 0, d_out)
+    for p in (d_pose, d_fr, d_out):
+        eng.dev_free(p)
+    eng.close()

@@ -80,12 +80,24 @@ def test_handlers_to_qdot_through_ports(net):
     yarp.Network.connect("/user/jointcmd", bases[1] + "/bridge/jointcmd")
     jcmd = rng.normal(size=7)
     _send(jc, jcmd)
+    dist_probe = _open(yarp, "/probe/distOut")
+    yarp.Network.connect(bases[0] + "/dmonitor/distOut", "/probe/distOut")
     for f in feeders:
         f.spin_once()
     for k in range(3):
         _send(enc[k], q[k])
     got = cc.cycle()
     assert got.all()
+    # /dmonitor/distOut of arm 0: the goal (object 0) and the obstacle (object 1), monitor_distance:156-167
+    from oracle import vfik_numpy as vn
+    db = dist_probe.read(False)
+    obstacle16 = [1.0, 0, 0, 0.3, 0, 1, 0, -0.2, 0, 0, 1, 0.6, 0, 0, 0, 1]
+    want = vn.object_distances(cc.last["pose"][0], {0: goals[0], 1: obstacle16})
+    assert db is not None and db.size() == 2
+    for k, (oid, dxyz, dang) in enumerate(want):
+        item = db.get(k).asList()
+        assert item.get(0).asDouble() == float(oid)
+        assert abs(item.get(1).asDouble() - dxyz) < 1e-12 and abs(item.get(2).asDouble() - dang) < 1e-9
     # oracle with the same state
     F = np.zeros((3, 4), dtype=_abi.FIELD_DTYPE)
     n = np.zeros(3, dtype=np.int32)

@@ -598,6 +598,16 @@ int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out
     return VFIK_OK;
 }
 
+int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, int max_objects, void* out) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!pose || !frames || !out) return fail(VFIK_E_ARG, "vfik_object_distances: pose, frames and out are required");
+    if (max_objects < 1 || max_objects > 4096) return fail(VFIK_E_ARG, "max_objects %d outside [1, 4096]", max_objects);
+    HIP_TRY(hipSetDevice(h->device));
+    hipError_t e = vfik::launch_monitor(h->io_dtype, pose, frames, max_objects, (long)h->B * max_objects, out, h->stream);
+    if (e != hipSuccess) return fail(VFIK_E_HIP, "monitor launch: %s", hipGetErrorString(e));
+    return VFIK_OK;
+}
+
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!cmds || !weights || !out || K < 1 || K > 16) return fail(VFIK_E_ARG, "vfik_mix: bad arguments (K=%d)", K);

@@ -1272,6 +1272,37 @@ __global__ void __launch_bounds__(256) track_kernel(const T* pose, const T* v6, 
     st[36 * Bs + arm] = cnt + 1.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Distance monitor of scripts/monitor_distance (monitor_distance:76-84,148-167), batched: for every arm
+// and every object frame it was told about (/dmonitor/objectsIn: the goal is object 0, obstacles
+// follow), the xyz distance between the tool pose and the object and the rotation angle between their
+// orientations, in DEGREES (orientLength = |diff(current, final).rot| * 180/pi).  One thread per
+// (arm, object); pose [B][16], frames [B][O][16], out [B][O][2].  A diagnostic: it never feeds qdot.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) monitor_kernel(const T* pose, const T* frames, int O, long count, T* out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const long arm = t / O;
+    double P[12], F[12];
+    const T* pp = pose + arm * 16;
+    const T* fp = frames + t * 16;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { P[k] = (double)pp[k]; F[k] = (double)fp[k]; }
+    const double dx = P[3] - F[3], dy = P[7] - F[7], dz = P[11] - F[11];
+    // relative rotation E = R_cur^T R_obj; its angle is what |diff().rot| measures
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E[3 * i + j] = P[i] * F[j] + P[4 + i] * F[4 + j] + P[8 + i] * F[8 + j];
+    const double a0 = 0.5 * (E[7] - E[5]), a1 = 0.5 * (E[2] - E[6]), a2 = 0.5 * (E[3] - E[1]);
+    const double c = 0.5 * (E[0] + E[4] + E[8] - 1.0);
+    const double sn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    out[2 * t] = (T)sqrt(dx * dx + dy * dy + dz * dz);
+    out[2 * t + 1] = (T)(atan2(sn, c) * 57.295779513082320877);
+}
+
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
     if (a.n_cycles > 0) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true>), grid, blk, lds, stream, a);
@@ -1474,6 +1505,18 @@ hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K
 }  // namespace vfik
 
 namespace vfik {
+hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream) {
+    const int block = 256;
+    const dim3 grid((unsigned)((count + block - 1) / block)), blk(block);
+    if (io_dtype == 32)
+        hipLaunchKernelGGL(monitor_kernel<float>, grid, blk, 0, stream, static_cast<const float*>(pose),
+                           static_cast<const float*>(frames), O, count, static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(monitor_kernel<double>, grid, blk, 0, stream, static_cast<const double*>(pose),
+                           static_cast<const double*>(frames), O, count, static_cast<double*>(out));
+    return hipGetLastError();
+}
+
 hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, int B, hipStream_t stream) {
     const int block = 256;
     const dim3 grid((B + block - 1) / block), blk(block);

@@ -78,6 +78,7 @@ def load_library(path=None):
         "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "vfik_slots_in_use": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
+        "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
@@ -313,6 +314,11 @@ class Engine:
 
     def d2h(self, arr, src):
         self._chk(self.lib.vfik_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src), arr.nbytes))
+
+    def object_distances(self, pose_dev, frames_dev, max_objects, out_dev):
+        """Distance monitor (monitor_distance:148-167) on device arrays: out[B][max_objects][2]."""
+        self._chk(self.lib.vfik_object_distances(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(frames_dev)), int(max_objects),
+                                                 C.c_void_p(_ptr(out_dev))))
 
     def track_error(self, pose_dev, v6_dev, out_dev):
         """One step of the tracking-error estimator (vf:349-428) on device arrays."""

@@ -110,6 +110,8 @@ class ControlCycleBatch:
         self.ext = np.zeros((4, self.B, self.n))
         self.ext_time = np.full((4, self.B), self.clock())
         self._ext_dirty = [False] * 4
+        self.objects = [dict() for _ in range(self.B)]   # monitor_distance:72: id -> frame16, insertion-ordered
+        self._mon_bufs = None
         self.q_ref = np.zeros((self.B, self.n))          # /jpctrl/ref (joint_p_controller:113-118)
         self.has_ref = np.zeros(self.B, dtype=bool)      # no reference yet: the controller commands nothing
         self.report_counter = 0  # vf:185,432-435
@@ -141,6 +143,7 @@ class ControlCycleBatch:
                 "current_weights": mk(br + "/current_weights"), "mixed": mk(br + "/mixed"),
                 "track_error": mk(vf + "/track_error"), "distOut": mk(base + "/dmonitor/distOut"),
                 "tracking_state": mk(base + "/dmonitor/tracking_state"),
+                "objectsIn": mk(base + "/dmonitor/objectsIn", True),
                 "jp_ref": mk(base + "/jpctrl/ref"), "jp_at_goal": mk(base + "/jpctrl/at_goal"),
             }
             for k in MIX_PORTS[2:]:
@@ -203,6 +206,14 @@ class ControlCycleBatch:
                         self._ext_dirty[ch] = True
                 elif b:
                     log.warning("arm %d: wrong length for data bottle on %s", a, name)
+            for b in self._drain(d["objectsIn"]):  # monitor_distance:111-129
+                if b.size() >= 2:
+                    if b.get(0).toString() == "add" and b.size() == 3:
+                        lst = b.get(2).asList()
+                        if lst is not None and lst.size() == 16:
+                            self.objects[a][b.get(1).asInt()] = [lst.get(i).asDouble() for i in range(16)]
+                    if b.get(0).toString() == "remove":
+                        self.objects[a].pop(b.get(1).asInt(), None)
             b = d["jp_ref"].read(False)  # joint_p_controller:113-118
             if b and b.size() == self.n:
                 self.q_ref[a] = _bottle_doubles(b)
@@ -265,6 +276,7 @@ class ControlCycleBatch:
         out = self.engine.step_host(self.q, null_control=self.control, q_ref=ref,
                                     want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist"))
         out["track_error"] = self._track_error(out)
+        dists = out["object_dist"] = self._object_distances(out)
         self.last = out
         self.report_counter += 1
         report = self.report_counter > 20  # vf:432-435
@@ -286,20 +298,23 @@ class ControlCycleBatch:
             te = out["track_error"][a]
             if te.any():                                      # from the 6th frame on (vf:354,418-428)
                 _send(d["track_error"], te[:7], ints=[int(te[7])])
-            if 1 in self.fields.sets[a]:                      # a goal exists: object 0 of /dmonitor/distOut
+            if self.objects[a]:                               # monitor_distance:156-172: one entry per object
                 b = d["distOut"].prepare()
                 b.clear()
-                item = b.addList()
-                item.addDouble(0.0)                           # monitor_distance:165 sends the id as a double
-                item.addDouble(float(out["goal_dist"][a, 0]))
-                item.addDouble(float(out["goal_dist"][a, 1]))
+                for slot, oid in enumerate(self.objects[a]):
+                    item = b.addList()
+                    item.addDouble(float(oid))                # monitor_distance:165 sends the id as a double
+                    item.addDouble(float(dists[a, slot, 0]))
+                    item.addDouble(float(dists[a, slot, 1]))
                 d["distOut"].write()
-                for kind, state in self.tracking[a].update(out["goal_dist"][a, 0], out["goal_dist"][a, 1], te[0], te[1]):
-                    sb = d["tracking_state"].prepare()
-                    sb.clear()
-                    sb.addString(kind)
-                    sb.addString(state)
-                    d["tracking_state"].writeStrict()
+                if 0 in self.objects[a]:                      # the goal: tracking state vote (monitor_distance:168-219)
+                    slot = list(self.objects[a]).index(0)
+                    for kind, state in self.tracking[a].update(dists[a, slot, 0], dists[a, slot, 1], te[0], te[1]):
+                        sb = d["tracking_state"].prepare()
+                        sb.clear()
+                        sb.addString(kind)
+                        sb.addString(state)
+                        d["tracking_state"].writeStrict()
         return got_q
 
     def _track_error(self, out):
@@ -313,6 +328,32 @@ class ControlCycleBatch:
         e.h2d(d_v6, out["v6"])
         e.track_error(d_pose, d_v6, d_out)
         res = np.zeros((self.B, 8), dtype=e.io_dtype)
+        e.d2h(res, d_out)
+        return res.astype(np.float64)
+
+    def _object_distances(self, out):
+        """The distance monitor (monitor_distance:148-167) for the batch, on the device: [B][O][2] with the
+        objects of every arm in the order of its dictionary; None while no arm knows any object."""
+        O = max(len(o) for o in self.objects)
+        if O == 0:
+            return None
+        e = self.engine
+        frames = np.tile(np.eye(4).reshape(16), (self.B, O, 1)).astype(e.io_dtype)
+        for a, objs in enumerate(self.objects):
+            for slot, oid in enumerate(objs):
+                frames[a, slot] = objs[oid]
+        esz = e.io_dtype.itemsize
+        if self._mon_bufs is None or self._mon_bufs[0] < O:
+            if self._mon_bufs is not None:
+                for p in self._mon_bufs[1:]:
+                    e.dev_free(p)
+            cap = max(O, 4)
+            self._mon_bufs = (cap, e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * cap * 16 * esz), e.dev_alloc(self.B * cap * 2 * esz))
+        _, d_pose, d_frames, d_out = self._mon_bufs
+        e.h2d(d_pose, np.ascontiguousarray(out["pose"], dtype=e.io_dtype))
+        e.h2d(d_frames, frames)
+        e.object_distances(d_pose, d_frames, O, d_out)
+        res = np.zeros((self.B, O, 2), dtype=e.io_dtype)
         e.d2h(res, d_out)
         return res.astype(np.float64)
 
