@@ -88,6 +88,12 @@ int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
 int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field* fields,
                     int max_fields, const int32_t* counts);
 
+/* Per-arm IK weights: what each arm's vf process keeps after a /weight message (vf:164-179,295-309): 't' + 6
+ * task-space weights -> wy[n_arms][6], 'j' + n joint-space weights -> wq[n_arms][n]; either may be NULL
+ * (unchanged).  Arms never written use vfik_params.wy / wq; a later vfik_set_params that CHANGES wy or wq
+ * is batch-wide again and replaces every arm's own weights. */
+int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double* wy, const double* wq);
+
 /* Per-arm mixer weights, w[n_arms][6]: what each arm's bridge keeps after a /bridge/weight message
  * (command_mixer.py:48-53; handlers send [cart, null, joint, 0], handlers.py:189-204).  NULL returns every
  * arm to the batch-wide vfik_params.mix_w. */

@@ -258,6 +258,45 @@ def test_tool_shared_and_per_arm_weights_and_params(env):
     _compare(got, ref, TOL64, ALL)
 
 
+@pytest.mark.parametrize("robot,dt,tol", [("lwr", np.float64, 1e-9), ("lwr", np.float32, 2e-5), ("lwr_dual14", np.float64, 1e-9)])
+def test_ik_weights_of_each_arm(env, robot, dt, tol):
+    """Every arm's vf process keeps its own 't' / 'j' weights (vf:164-179,295-309): three groups of arms with
+    different weights in one batch, each compared with the oracle run on that group's weights."""
+    chain = env.robots.by_name(robot)
+    n, B = chain.n, 192
+    f = env.abi
+    flags = f.F_NULLSPACE | f.F_MIXER
+    w = env.synth.make_workload(chain, B, 3, seed=16, io_dtype=dt)
+    rng = np.random.default_rng(16)
+    groups = [(slice(0, 64), [1.0] * 6, [1.0] * n),                                   # untouched arms: the batch weights
+              (slice(64, 128), [1, 1, 1, 0.2, 0.2, 0.05], [1.0] * n),                 # 't' only
+              (slice(128, 192), [0.5, 1, 1, 1, 0.3, 1], list(rng.uniform(0.1, 1.0, n)))]  # 't' and 'j'
+    params = f.default_params(flags=flags)
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_arm_weights(wy=np.tile(groups[1][1], (64, 1)), first_arm=64)
+    eng.set_arm_weights(wy=np.tile(groups[2][1], (64, 1)), wq=np.tile(groups[2][2], (64, 1)), first_arm=128)
+    want = ("qdot_vf", "qdot_out", "status")
+    got = eng.step_host(w["q"], want=want)
+    for sl, wy, wq in groups:
+        p = f.default_params(flags=flags, wy=wy, wq=wq + [1.0] * (16 - n))
+        ref = env.oc.cycle_batch(chain, p, w["q"][sl], w["fields"][sl], w["nfields"][sl])
+        for k in ("qdot_vf", "qdot_out"):
+            assert np.abs(got[k][sl] - ref[k]).max() < tol, (k, sl)
+    # the groups really differ, and batch-wide weights set afterwards take every arm back
+    assert np.abs(got["qdot_vf"][64:128] - env.oc.cycle_batch(chain, params, w["q"][64:128], w["fields"][64:128], w["nfields"][64:128])["qdot_vf"]).max() > 1e-3
+    eng.set_params(wy=[1, 1, 1, 0.5, 0.5, 0.5])
+    got = eng.step_host(w["q"], want=want)
+    p = f.default_params(flags=flags, wy=[1, 1, 1, 0.5, 0.5, 0.5])
+    ref = env.oc.cycle_batch(chain, p, w["q"], w["fields"], w["nfields"])
+    assert np.abs(got["qdot_vf"] - ref["qdot_vf"]).max() < tol
+    with pytest.raises(env.engine.VfikError):
+        eng.set_arm_weights(wy=np.full((1, 6), np.nan))
+    with pytest.raises(env.engine.VfikError):
+        eng.set_arm_weights(wy=np.ones((2, 6)), first_arm=B - 1)
+    eng.close()
+
+
 # ---- nullspace module ---------------------------------------------------------------------------------------
 def test_nullspace_sign_memory_over_a_trajectory(env):
     """Stateful parity: 40 cycles along a joint trajectory, /control active (nullspace:95-117)."""

@@ -256,3 +256,54 @@ def test_joint_controller_through_ports(net):
     assert b.get(0).asInt() == 1
     assert np.abs(qa - np.clip(ref, chain.q_lo, chain.q_hi)).max() < 0.02
     cc.close()
+
+
+def test_weight_port_sets_the_weights_of_that_arm_only(net):
+    """HandleBridge.set_weights -> /vectorField/weight ('t'/'j' bottles, vf:295-309) reaches one arm."""
+    yarp = net
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots
+    from vfclik_amd.handlers import HandleArmNew
+    from vfclik_amd.object_feeder import ObjectFeeder
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    arms = ["/right", "/left"]
+    bases = ["/0/lwr" + a for a in arms]
+    cc = ControlCycleBatch(chain, bases, io_dtype=np.float64)
+    feeders = [ObjectFeeder(b) for b in bases]
+    handles = [HandleArmNew(arm=a) for a in arms]
+    rng = np.random.default_rng(21)
+    q = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (2, 7))
+    goals = chain.fk(rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (2, 7))).reshape(2, 16)
+    enc = [_open(yarp, "/sim%s/encoders" % a) for a in arms]
+    outs = [_open(yarp, "/probe%d/qdot" % k) for k in range(2)]
+    for k, b in enumerate(bases):
+        yarp.Network.connect("/sim%s/encoders" % arms[k], b + "/vectorField/qIn")
+        yarp.Network.connect(b + "/vectorField/qdotOut", "/probe%d/qdot" % k)
+        handles[k].go_cart([float(x) for x in goals[k]])
+    wy = [1, 1, 1, 0.1, 0.1, 0.1]
+    wq = [1, 0.5, 1, 0.5, 1, 0.2, 1]
+    handles[1].set_wik_cart_weights(wy)
+    handles[1].set_wik_joint_weights(wq)
+    handles[0].set_wik_joint_weights(wq[:5])  # wrong length: warned about and ignored (vf:176-179)
+    for f in feeders:
+        f.spin_once()
+    for k in range(2):
+        _send(enc[k], q[k])
+    assert cc.cycle().all()
+    for k in range(2):
+        p = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+        if k == 1:
+            for i in range(6):
+                p.wy[i] = wy[i]
+            for i in range(7):
+                p.wq[i] = wq[i]
+        F = np.zeros((1, 1), dtype=_abi.FIELD_DTYPE)
+        F[0, 0]["id"], F[0, 0]["type"], F[0, 0]["force"] = 1, 1, 1.0
+        F[0, 0]["p"][:16] = goals[k]
+        F[0, 0]["p"][16] = 0.1
+        ref = oracle_c.cycle_batch(chain, p, q[k:k + 1], F, np.ones(1, dtype=np.int32))
+        assert np.abs(_read(outs[k]) - ref["qdot_vf"][0]).max() < 1e-9, k
+    cc.close()
+    for f in feeders:
+        f.close()

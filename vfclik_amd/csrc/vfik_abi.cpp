@@ -68,6 +68,7 @@ struct vfik_handle {
     int* d_sig = nullptr;      // [B]
     double* d_mixw = nullptr;  // [16]
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    double* d_wts = nullptr;    // per-arm IK weights [6 + n][Bpad], allocated by vfik_set_arm_weights
     double* d_track = nullptr;  // tracking-error history [38][B], allocated on first use
     void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
@@ -151,7 +152,8 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.fast_order = h->fast_order;
     a.flags = h->params.flags;
     a.tool_stride = h->tool_per_arm ? h->Bpad : 0;
-    a.plain = (h->plain && !h->tool_per_arm) ? 1 : 0;
+    a.plain = (h->plain && !h->tool_per_arm && !h->d_wts) ? 1 : 0;
+    a.wts = h->d_wts;
     a.q = io->q;
     a.goal = h->d_goal;
     a.slots = h->d_slots;
@@ -291,7 +293,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -338,7 +340,16 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     if ((p->flags & VFIK_F_JOINT_LIMIT_TASK) && !(p->flags & VFIK_F_NULLSPACE))
         return fail(VFIK_E_ARG, "VFIK_F_JOINT_LIMIT_TASK needs VFIK_F_NULLSPACE");
     const bool speed_changed = !h->speed_set || p->speed_scale != h->params.speed_scale;
+    bool weights_changed = false;
+    for (int k = 0; k < 6; ++k) weights_changed = weights_changed || p->wy[k] != h->params.wy[k];
+    for (int k = 0; k < h->n; ++k) weights_changed = weights_changed || p->wq[k] != h->params.wq[k];
     h->params = *p;
+    if (weights_changed && h->d_wts) {  // new batch-wide IK weights replace every arm's own
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_wts);
+        h->d_wts = nullptr;
+    }
     if (speed_changed) {  // vfik_params.speed_scale is the batch-wide /max_vel value: written to every arm
         std::vector<double> all(h->B, p->speed_scale);
         const int rc = vfik_set_speed_scale(h, 0, h->B, all.data());
@@ -346,6 +357,46 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
         h->speed_set = true;
     }
     return upload_kconst(h);
+}
+
+// device image of the per-arm IK weights: [6 + n][Bpad] doubles, every arm starting from the batch's
+static int ensure_arm_weights(vfik_handle* h) {
+    if (h->d_wts) return VFIK_OK;
+    const size_t Bp = h->Bpad, rows = 6 + h->n;
+    std::vector<double> img(rows * Bp, 1.0);
+    for (size_t r = 0; r < rows; ++r) {
+        const double v = r < 6 ? h->params.wy[r] : h->params.wq[r - 6];
+        for (size_t b = 0; b < Bp; ++b) img[r * Bp + b] = v;
+    }
+    if (dev_alloc(h, (void**)&h->d_wts, img.size() * sizeof(double), false)) return VFIK_E_HIP;
+    HIP_TRY(hipMemcpyAsync(h->d_wts, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
+int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double* wy, const double* wq) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    if (!wy && !wq) return fail(VFIK_E_ARG, "vfik_set_arm_weights: give wy, wq or both");
+    for (int j = 0; j < n_arms; ++j) {
+        for (int k = 0; wy && k < 6; ++k)
+            if (!std::isfinite(wy[(size_t)j * 6 + k])) return fail(VFIK_E_ARG, "arm %d: task weight %d is not finite", first_arm + j, k);
+        for (int k = 0; wq && k < h->n; ++k)
+            if (!std::isfinite(wq[(size_t)j * h->n + k])) return fail(VFIK_E_ARG, "arm %d: joint weight %d is not finite", first_arm + j, k);
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if (ensure_arm_weights(h) != VFIK_OK) return VFIK_E_HIP;
+    const size_t Bp = h->Bpad;
+    std::vector<double> row(n_arms);
+    for (int r = 0; r < 6 + h->n; ++r) {
+        const double* src = r < 6 ? wy : wq;
+        if (!src) continue;
+        const int stride = r < 6 ? 6 : h->n, col = r < 6 ? r : r - 6;
+        for (int j = 0; j < n_arms; ++j) row[j] = src[(size_t)j * stride + col];
+        HIP_TRY(hipMemcpyAsync(h->d_wts + (size_t)r * Bp + first_arm, row.data(), n_arms * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // `row` is reused
+    }
+    return VFIK_OK;
 }
 
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {

@@ -79,6 +79,7 @@ struct KArgs {
     const void* null_control;
     const void* ext;
     const void* mixw;  // per-arm mixer weights, 2 quad planes, or NULL (KConst::mix_w for every arm)
+    const double* wts;    // per-arm IK weights [6 + n][Bpad] (wy rows, then wq rows), or NULL (KConst::wy / wq)
     const void* q_ref;    // [B][n] joint P controller reference (mixer channel 2), or NULL
     const void* q_cmded;  // [B][n] LWR echo of the commanded position (bridge:199-203 command form), or NULL
     double* lastvec;

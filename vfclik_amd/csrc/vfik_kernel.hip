@@ -765,15 +765,20 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
     double qv[NJ];
     {
-        // Jw' = Wy J Wq, kept as scaled columns (the PLAIN variant uses J itself)
+        // Jw' = Wy J Wq, kept as scaled columns (the PLAIN variant uses J itself).  The weights are the
+        // batch's (KConst) or, once vfik_set_arm_weights was used, the arm's own row of a.wts.
+        const double* wts = a.wts ? a.wts + arm : nullptr;
+        const long wpitch = a.Bpad;
+        auto WY = [&](int r) { return wts ? wts[(long)r * wpitch] : kc->wy[r]; };
+        auto WQ = [&](int i) { return wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i]; };
         double Sw[PLAIN ? 1 : NJ][6];
         if (!PLAIN) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
-                    Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
+                    Sw[PLAIN ? 0 : i][r] = WY(r) * Jm[i][r] * WQ(i);
+                    Sw[PLAIN ? 0 : i][3 + r] = WY(3 + r) * Jm[i][3 + r] * WQ(i);
                 }
             }
         }
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = PLAIN ? tw[i] : kc->wy[i] * tw[i];
+            double t = PLAIN ? tw[i] : WY(i) * tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -833,7 +838,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             for (int i = 0; i < NJ; ++i) qv[i] = __builtin_fma(S[i][r], y[r], qv[i]);
         if (!PLAIN) {
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) qv[i] *= kc->wq[i];
+            for (int i = 0; i < NJ; ++i) qv[i] *= WQ(i);
         }
     }
 

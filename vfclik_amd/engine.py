@@ -78,6 +78,7 @@ def load_library(path=None):
         "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "vfik_slots_in_use": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
+        "vfik_set_arm_weights": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     }
     for name, (res, args) in protos.items():
@@ -314,6 +315,24 @@ class Engine:
 
     def d2h(self, arr, src):
         self._chk(self.lib.vfik_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src), arr.nbytes))
+
+    def set_arm_weights(self, wy=None, wq=None, first_arm=0):
+        """Per-arm IK weights (vf:295-309): wy (n_arms, 6) and/or wq (n_arms, n) starting at first_arm."""
+        arrs = []
+        for w, cols in ((wy, 6), (wq, self.n)):
+            if w is None:
+                arrs.append(None)
+                continue
+            a = np.ascontiguousarray(w, dtype=np.float64)
+            if a.ndim != 2 or a.shape[1] != cols:
+                raise ValueError("weights must be (n_arms, %d), got %s" % (cols, a.shape))
+            arrs.append(a)
+        counts = {a.shape[0] for a in arrs if a is not None}
+        if len(counts) != 1:
+            raise ValueError("wy and wq must cover the same arms")
+        self._chk(self.lib.vfik_set_arm_weights(self.h, int(first_arm), counts.pop(),
+                                                None if arrs[0] is None else arrs[0].ctypes.data,
+                                                None if arrs[1] is None else arrs[1].ctypes.data))
 
     def object_distances(self, pose_dev, frames_dev, max_objects, out_dev):
         """Distance monitor (monitor_distance:148-167) on device arrays: out[B][max_objects][2]."""

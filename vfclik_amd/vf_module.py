@@ -238,9 +238,7 @@ class ControlCycleBatch:
             out.append(b)
 
     def _handle_weight(self, arm, b):
-        """'t' + 6 or 'j' + n doubles (vf:164-179,296-309).  The IK weights are one set per handle:
-        a message on any arm's port sets them for the batch (arms that need their own weights belong
-        in their own ControlCycleBatch)."""
+        """'t' + 6 or 'j' + n doubles (vf:164-179,296-309): the weights of THIS arm's vf process."""
         kind = b.get(0).asString()
         n_vars = 6 if kind == "t" else self.n if kind == "j" else None
         if n_vars is None:
@@ -248,8 +246,8 @@ class ControlCycleBatch:
         if b.size() != n_vars + 1:
             log.warning("arm %d: wrong size of %s weights, ignored", arm, kind)
             return
-        w = [b.get(i + 1).asDouble() for i in range(n_vars)]
-        self.engine.set_params(**({"wy": w} if kind == "t" else {"wq": w}))
+        w = [[b.get(i + 1).asDouble() for i in range(n_vars)]]
+        self.engine.set_arm_weights(first_arm=arm, **({"wy": w} if kind == "t" else {"wq": w}))
 
     def _push_state(self):
         self.fields.flush(self.engine)
