@@ -763,37 +763,79 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     tw[3] = w[0]; tw[4] = w[1]; tw[5] = w[2];
 
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
+    // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
+    // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's two passes over the Jacobian -- G = J J^T
+    // and J z are accumulated with A, and J^T w is subtracted while J^T y is formed -- because for n = 14
+    // the Jacobian lives in AGPRs and every further pass costs 168 register moves.
+    constexpr bool FUSEP = NULLSP && NJ >= 8;
+    double zp[FUSEP ? NJ : 1];
     double qv[NJ];
     {
         // Jw' = Wy J Wq, kept as scaled columns (the PLAIN variant uses J itself).  The weights are the
         // batch's (KConst) or, once vfik_set_arm_weights was used, the arm's own row of a.wts.
-        const double* wts = a.wts ? a.wts + arm : nullptr;
+        const double* wts = (!PLAIN && a.wts) ? a.wts + arm : nullptr;
         const long wpitch = a.Bpad;
-        auto WY = [&](int r) { return wts ? wts[(long)r * wpitch] : kc->wy[r]; };
-        auto WQ = [&](int i) { return wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i]; };
         double Sw[PLAIN ? 1 : NJ][6];
         if (!PLAIN) {
+            if (wts) {  // wave-uniform: the arm's own weights, read where they are used
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
+                for (int i = 0; i < NJ; ++i) {
+                    const double wqi = wts[(long)(6 + i) * wpitch];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    Sw[PLAIN ? 0 : i][r] = WY(r) * Jm[i][r] * WQ(i);
-                    Sw[PLAIN ? 0 : i][3 + r] = WY(3 + r) * Jm[i][3 + r] * WQ(i);
+                    for (int r = 0; r < 6; ++r) Sw[PLAIN ? 0 : i][r] = wts[(long)r * wpitch] * Jm[i][r] * wqi;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
+                        Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
+                    }
                 }
             }
         }
         double (*const S)[6] = PLAIN ? Jm : Sw;
         double A[6][6];
+        double G[FUSEP ? 6 : 1][6], wn[6];  // FUSEP: undamped Gram matrix and J z of the projector
+        constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) A[r][c] = (r == c) ? kc->lambda2 : 0.0;
+            for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
+        if constexpr (FUSEP) {
+            const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) zp[i] = jlt ? -kc->jl_k[i] * (q[i] - kc->q_mid[i]) : 0.0;  // -jl_gain (q - mid) / half^2
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                wn[r] = 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 6; ++r) {
 #pragma unroll
                 for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
+                if constexpr (FUSEP) {
+                    wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
+                    if constexpr (!PLAIN) {
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
+                    }
+                }
+            }
+        if constexpr (GFROMA) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = A[r][c];
+                A[r][r] += kc->lambda2;
+            }
+        }
         // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
         double dinv[6];
 #pragma unroll
@@ -816,7 +858,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = PLAIN ? tw[i] : WY(i) * tw[i];
+            double t = PLAIN ? tw[i] : (wts ? wts[(long)i * wpitch] : kc->wy[i]) * tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -830,15 +872,59 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k];
             y[i] = t;
         }
+        if constexpr (FUSEP) {
+            // LDL^T of the undamped Gram matrix; a vanishing pivot (singular pose) drops that direction
+            // instead of dividing by it.  Then wn <- (J J^T)^-1 J z.
+            double (*const Gm)[6] = G;
+            double gmax = Gm[0][0];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) qv[i] = S[i][0] * y[0];
+            for (int r = 1; r < 6; ++r) gmax = fmax(gmax, Gm[FUSEP ? r : 0][r]);
+            double gi[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int jj = FUSEP ? j : 0;
+                double v[6];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v[k] = Gm[jj][k] * Gm[FUSEP ? k : 0][k];
+                double dj = Gm[jj][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj = __builtin_fma(-Gm[jj][k], v[k], dj);
+                const bool okp = dj > 1e-12 * gmax;
+                Gm[jj][j] = okp ? dj : 0.0;
+                gi[j] = okp ? rcp_nr(dj) : 0.0;
+#pragma unroll
+                for (int k = 0; k < j; ++k)
+#pragma unroll
+                    for (int i = j + 1; i < 6; ++i) Gm[FUSEP ? i : 0][j] = __builtin_fma(-Gm[FUSEP ? i : 0][k], v[k], Gm[FUSEP ? i : 0][j]);
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) Gm[FUSEP ? i : 0][j] *= gi[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) wn[i] = __builtin_fma(-Gm[FUSEP ? i : 0][k], wn[k], wn[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) wn[i] *= gi[i];
+#pragma unroll
+            for (int i = 5; i >= 0; --i)
+#pragma unroll
+                for (int k = i + 1; k < 6; ++k) wn[i] = __builtin_fma(-Gm[FUSEP ? k : 0][i], wn[k], wn[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            qv[i] = S[i][0] * y[0];
+            if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][0], wn[0], zp[i]);
+        }
 #pragma unroll
         for (int r = 1; r < 6; ++r)
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) qv[i] = __builtin_fma(S[i][r], y[r], qv[i]);
+            for (int i = 0; i < NJ; ++i) {
+                qv[i] = __builtin_fma(S[i][r], y[r], qv[i]);
+                if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][r], wn[r], zp[i]);
+            }
         if (!PLAIN) {
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) qv[i] *= WQ(i);
+            for (int i = 0; i < NJ; ++i) qv[i] *= wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i];
         }
     }
 
@@ -852,11 +938,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         // Keep the compiler from starting this module before the IK has finished with Jm: interleaved,
         // the two keep two copies of the Jacobian alive and (n = 14) spill to scratch.  No instruction
         // is emitted: the empty asm only ties every Jm element to the IK result.
-#pragma unroll
-        for (int i = 0; i < NJ; ++i)
-#pragma unroll
-            for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
         if constexpr (NJ <= 7) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
             // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
             // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
             // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
@@ -977,66 +1063,10 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         } else {
             // n >= 8: the nullspace of a 6 x n Jacobian has dimension >= 2, so the reference's SVD basis is
             // never unique and /control is never honoured; only the projector is needed (joint-limit task):
-            // (I - J^+ J) z = z - J^T (J J^T)^-1 J z with an LDL^T of the undamped Gram matrix.  A vanishing
-            // pivot (singular pose) drops that direction instead of dividing by it.
+            // (I - J^+ J) z = z - J^T (J J^T)^-1 J z, computed with the IK above (FUSEP).
             status |= VFIK_ST_NULL_AMBIGUOUS;
-            if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
-                double z[NJ], G[6][6], wv[6];
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    wv[r] = 0.0;
-#pragma unroll
-                    for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
-                }
-#pragma unroll
-                for (int i = 0; i < NJ; ++i)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        wv[r] = __builtin_fma(Jm[i][r], z[i], wv[r]);
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) G[r][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[r][c]);
-                    }
-                double gmax = G[0][0];
-#pragma unroll
-                for (int r = 1; r < 6; ++r) gmax = fmax(gmax, G[r][r]);
-                double gi[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    double v[6];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) v[k] = G[j][k] * G[k][k];
-                    double dj = G[j][j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], v[k], dj);
-                    const bool okp = dj > 1e-12 * gmax;
-                    G[j][j] = okp ? dj : 0.0;
-                    gi[j] = okp ? rcp_nr(dj) : 0.0;
-#pragma unroll
-                    for (int k = 0; k < j; ++k)
-#pragma unroll
-                        for (int i = j + 1; i < 6; ++i) G[i][j] = __builtin_fma(-G[i][k], v[k], G[i][j]);
-#pragma unroll
-                    for (int i = j + 1; i < 6; ++i) G[i][j] *= gi[j];
-                }
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int k = 0; k < i; ++k) wv[i] = __builtin_fma(-G[i][k], wv[k], wv[i]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) wv[i] *= gi[i];
-#pragma unroll
-                for (int i = 5; i >= 0; --i)
-#pragma unroll
-                    for (int k = i + 1; k < 6; ++k) wv[i] = __builtin_fma(-G[k][i], wv[k], wv[i]);
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) z[i] = __builtin_fma(-Jm[i][r], wv[r], z[i]);
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) qn[i] += z[i];
-            }
+            for (int i = 0; i < NJ; ++i) qn[i] += zp[FUSEP ? i : 0];
         }
         // check_limits (nullspace:120-131) then gain (nullspace:183)
         bool stop = false;
