@@ -644,6 +644,103 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
 
+    // ---------------- A7 (first half): the IK's normal matrix and its factorisation -------------
+    // A = Jw Jw^T + lambda^2 I depends on q alone, not on the field: for chains of up to 7 joints it is
+    // factorised BEFORE the field is evaluated (registers permitting), which frees the Jacobian-sized
+    // working set early and leaves only the two triangular solves after the field.  Measured neutral on
+    // C3 (7.05-7.14 us per launch either way): the pivot chain is not what the wave waits for.
+    constexpr bool EARLY_FACTOR = NJ <= 7;
+    // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
+    // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's two passes over the Jacobian -- G = J J^T
+    // and J z are accumulated with A, and J^T w is subtracted while J^T y is formed -- because for n = 14
+    // the Jacobian lives in AGPRs and every further pass costs 168 register moves.
+    constexpr bool FUSEP = NULLSP && NJ >= 8;
+    double zp[FUSEP ? NJ : 1];
+    const double* wts = (!PLAIN && a.wts) ? a.wts + arm : nullptr;
+    const long wpitch = a.Bpad;
+    double Sw[PLAIN ? 1 : NJ][6];
+    double A[6][6], dinv[6];
+    double G[FUSEP ? 6 : 1][6], wn[6];  // FUSEP: undamped Gram matrix and J z of the projector
+    double (*const S)[6] = PLAIN ? Jm : Sw;
+    auto ik_factor = [&]() {
+        if (!PLAIN) {
+            if (wts) {  // wave-uniform: the arm's own weights, read where they are used
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    const double wqi = wts[(long)(6 + i) * wpitch];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) Sw[PLAIN ? 0 : i][r] = wts[(long)r * wpitch] * Jm[i][r] * wqi;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
+                        Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
+                    }
+                }
+            }
+        }
+        constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
+        if constexpr (FUSEP) {
+            const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) zp[i] = jlt ? -kc->jl_k[i] * (q[i] - kc->q_mid[i]) : 0.0;  // -jl_gain (q - mid) / half^2
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                wn[r] = 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
+                if constexpr (FUSEP) {
+                    wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
+                    if constexpr (!PLAIN) {
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
+                    }
+                }
+            }
+        if constexpr (GFROMA) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = A[r][c];
+                A[r][r] += kc->lambda2;
+            }
+        }
+        // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v[6];  // v_k = L_jk d_k
+#pragma unroll
+            for (int k = 0; k < j; ++k) v[k] = A[j][k] * A[k][k];
+            double dj = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dj = __builtin_fma(-A[j][k], v[k], dj);
+            A[j][j] = dj;
+            dinv[j] = rcp_nr(dj);
+#pragma unroll
+            for (int k = 0; k < j; ++k)  // rows below j, one k at a time: the rows are independent chains
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) A[i][j] = __builtin_fma(-A[i][k], v[k], A[i][j]);
+#pragma unroll
+            for (int i = j + 1; i < 6; ++i) A[i][j] *= dinv[j];
+        }
+    };
+    if constexpr (EARLY_FACTOR) ik_factor();
+
     // ---------------- A5: vector field at the tool pose (vf:276-293,344-347) -------------------
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
     double gdist[2] = {0.0, 0.0};  // distance and rotation angle to the goal (monitor_distance:161-167)
@@ -763,98 +860,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     tw[3] = w[0]; tw[4] = w[1]; tw[5] = w[2];
 
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
-    // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
-    // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's two passes over the Jacobian -- G = J J^T
-    // and J z are accumulated with A, and J^T w is subtracted while J^T y is formed -- because for n = 14
-    // the Jacobian lives in AGPRs and every further pass costs 168 register moves.
-    constexpr bool FUSEP = NULLSP && NJ >= 8;
-    double zp[FUSEP ? NJ : 1];
     double qv[NJ];
     {
-        // Jw' = Wy J Wq, kept as scaled columns (the PLAIN variant uses J itself).  The weights are the
-        // batch's (KConst) or, once vfik_set_arm_weights was used, the arm's own row of a.wts.
-        const double* wts = (!PLAIN && a.wts) ? a.wts + arm : nullptr;
-        const long wpitch = a.Bpad;
-        double Sw[PLAIN ? 1 : NJ][6];
-        if (!PLAIN) {
-            if (wts) {  // wave-uniform: the arm's own weights, read where they are used
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    const double wqi = wts[(long)(6 + i) * wpitch];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) Sw[PLAIN ? 0 : i][r] = wts[(long)r * wpitch] * Jm[i][r] * wqi;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
-                        Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
-                    }
-                }
-            }
-        }
-        double (*const S)[6] = PLAIN ? Jm : Sw;
-        double A[6][6];
-        double G[FUSEP ? 6 : 1][6], wn[6];  // FUSEP: undamped Gram matrix and J z of the projector
-        constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
-        if constexpr (FUSEP) {
-            const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) zp[i] = jlt ? -kc->jl_k[i] * (q[i] - kc->q_mid[i]) : 0.0;  // -jl_gain (q - mid) / half^2
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                wn[r] = 0.0;
-#pragma unroll
-                for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
-                if constexpr (FUSEP) {
-                    wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
-                    if constexpr (!PLAIN) {
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
-                    }
-                }
-            }
-        if constexpr (GFROMA) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = A[r][c];
-                A[r][r] += kc->lambda2;
-            }
-        }
-        // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
-        double dinv[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double v[6];  // v_k = L_jk d_k
-#pragma unroll
-            for (int k = 0; k < j; ++k) v[k] = A[j][k] * A[k][k];
-            double dj = A[j][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) dj = __builtin_fma(-A[j][k], v[k], dj);
-            A[j][j] = dj;
-            dinv[j] = rcp_nr(dj);
-#pragma unroll
-            for (int k = 0; k < j; ++k)  // rows below j, one k at a time: the rows are independent chains
-#pragma unroll
-                for (int i = j + 1; i < 6; ++i) A[i][j] = __builtin_fma(-A[i][k], v[k], A[i][j]);
-#pragma unroll
-            for (int i = j + 1; i < 6; ++i) A[i][j] *= dinv[j];
-        }
+        if constexpr (!EARLY_FACTOR) ik_factor();
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
