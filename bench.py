@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
+    ap.add_argument("--host-path", type=int, default=100, help="also time this many steps with q/qdot in host memory (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the real thing; gloo + --single-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -171,6 +172,35 @@ def main():
                    "us_per_cycle": r_ms * 1e3 / (launches * args.rollout),
                    "cycles_per_s": world * B * launches * args.rollout / (r_ms * 1e-3)}
 
+    # secondary figure (never `value`): the PCIe-inclusive rate when q and qdot live in HOST memory, as they do
+    # for a host that talks to robots -- synchronous pageable copies vs the three-stream pipeline on pinned buffers
+    host_path = None
+    if world == 1 and args.host_path > 0:
+        hq = eng.host_array((B, chain.n))
+        hq[:] = w["q"].astype(io_dtype)
+        houts = [{"qdot_out": eng.host_array((B, chain.n))} for _ in range(3)]
+        for k in range(3):
+            eng.wait(eng.submit_host(hq, houts[k]))
+        t1 = time.perf_counter()
+        tickets = []
+        for k in range(args.host_path):
+            if len(tickets) == 3:
+                eng.wait(tickets.pop(0))
+            tickets.append(eng.submit_host(hq, houts[k % 3]))
+        for t in tickets:
+            eng.wait(t)
+        piped = time.perf_counter() - t1
+        qn = w["q"].astype(io_dtype)
+        eng.step_host(qn)
+        reps = max(3, args.host_path // 10)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.step_host(qn)
+        synced = time.perf_counter() - t1
+        host_path = {"pipelined_pinned_cycles_per_s": B * args.host_path / piped, "pipelined_us_per_step": piped * 1e6 / args.host_path,
+                     "sync_pageable_cycles_per_s": B * reps / synced, "sync_us_per_step": synced * 1e6 / reps,
+                     "bytes_per_step_each_way": int(B * chain.n * io_dtype.itemsize), "in_flight": 3}
+
     gathered = None
     if args.gather and world > 1:
         # optional collation of the per-rank results (NOT part of the control path): one all_gather
@@ -221,6 +251,8 @@ def main():
         }
         if rollout is not None:
             line["rollout"] = rollout
+        if host_path is not None:
+            line["host_path"] = host_path
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(chain, params, w)
             line["cpu_baseline"]["numpy_ref_style_loop_cycles_per_s_1proc"] = numpy_loop_rate(chain, params, w)

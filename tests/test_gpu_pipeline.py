@@ -1,0 +1,75 @@
+"""Pipelined host path (vfik_submit_host / vfik_wait): the same numbers as the synchronous path, in
+submission order (stateful nullspace sign memory included), with several submissions in flight."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, engine, robots, synth
+    return dict(oc=oracle_c, abi=_abi, engine=engine, robots=robots, synth=synth)
+
+
+@pytest.mark.parametrize("dt,pinned", [(np.float64, True), (np.float32, True), (np.float64, False)])
+def test_pipeline_matches_the_oracle_in_submission_order(env, dt, pinned):
+    abi = env["abi"]
+    chain = env["robots"].lwr()
+    B, K = 777, 8
+    w = env["synth"].make_workload(chain, B, 4, seed=23, io_dtype=dt)
+    params = abi.default_params(flags=abi.F_NULLSPACE | abi.F_MIXER)
+    eng = env["engine"].Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    rng = np.random.default_rng(4)
+    mk = (lambda shape, d=dt: eng.host_array(shape, d)) if pinned else (lambda shape, d=dt: np.zeros(shape, dtype=d))
+    qs, ctrls, outs, tickets = [], [], [], []
+    q = w["q"].astype(dt)
+    for k in range(K):  # K different joint states, all submitted before the first wait
+        qk, ck = mk((B, 7)), mk((B, 4))
+        qk[:] = np.clip(q + 0.05 * k * rng.normal(size=(B, 7)), 0.9 * chain.q_lo, 0.9 * chain.q_hi)
+        ck[:] = rng.uniform(-1, 1, (B, 4))
+        o = {"qdot_out": mk((B, 7)), "qdot_null": mk((B, 7)), "pose": mk((B, 16)), "status": mk((B,), np.int32)}
+        qs.append(qk); ctrls.append(ck); outs.append(o)
+        tickets.append(eng.submit_host(qk, o, null_control=ck))
+    assert tickets == list(range(K))
+    for t in reversed(tickets):  # waiting out of order is allowed
+        eng.wait(t)
+    eng.wait(tickets[0])  # and waiting twice is harmless
+    states = env["oc"].new_states(B, 7)
+    tol = 1e-9 if dt == np.float64 else 2e-5
+    for k in range(K):  # the sign memory advanced in submission order
+        ref = env["oc"].cycle_batch(chain, params, qs[k].astype(np.float64), w["fields"], w["nfields"],
+                                    null_control=ctrls[k].astype(np.float64), states=states)
+        assert np.abs(outs[k]["qdot_out"] - ref["qdot_out"]).max() < tol, k
+        assert np.abs(outs[k]["qdot_null"] - ref["qdot_null"]).max() < tol, k
+        assert np.abs(outs[k]["pose"] - ref["pose"]).max() < (1e-12 if dt == np.float64 else 1e-6)
+        assert np.array_equal(outs[k]["status"], ref["status"])
+    with pytest.raises(env["engine"].VfikError):
+        eng.wait(K + 5)
+    with pytest.raises(ValueError):
+        eng.submit_host(qs[0][:, :6], outs[0])
+    eng.close()
+
+
+def test_pipeline_and_synchronous_path_interleave(env):
+    """A synchronous vfik_step_host between two submissions sees and leaves consistent state."""
+    abi = env["abi"]
+    chain = env["robots"].lwr()
+    B = 300
+    w = env["synth"].make_workload(chain, B, 2, seed=5, io_dtype=np.float64)
+    eng = env["engine"].Engine(chain, B, io_dtype=np.float64, max_slots=4, params=abi.default_params())
+    eng.set_fields(w["fields"], w["nfields"])
+    q = eng.host_array((B, 7))
+    q[:] = w["q"]
+    o1, o2 = {"qdot_out": eng.host_array((B, 7))}, {"qdot_out": eng.host_array((B, 7))}
+    t1 = eng.submit_host(q, o1)
+    mid = eng.step_host(w["q"])
+    t2 = eng.submit_host(q, o2)
+    eng.wait(t2)
+    eng.wait(t1)
+    assert np.array_equal(o1["qdot_out"], mid["qdot_out"]) and np.array_equal(o2["qdot_out"], mid["qdot_out"])
+    eng.close()

@@ -83,6 +83,17 @@ struct vfik_handle {
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     Scratch sc[14];
+    // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
+    // its own device staging buffers and events; s_in / s_out are the side streams
+    static constexpr int PIPE = 3;
+    struct PipeSlot {
+        Scratch sc[14];
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+        long ticket = -1;  // submission living in this slot, -1 = free
+    };
+    PipeSlot pipe[PIPE];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    long next_ticket = 0;
 };
 
 namespace {
@@ -92,6 +103,24 @@ int dev_alloc(vfik_handle* h, void** p, size_t bytes, bool zero) {
     h->dev_bytes += bytes;
     if (zero) HIP_TRY(hipMemsetAsync(*p, 0, bytes, h->stream));
     return VFIK_OK;
+}
+
+// A setter rewrites device state that kernels of the pipelined host path may still be reading on the
+// side streams: let those drain first (the handle's own stream is synchronised by the setters themselves).
+int quiesce(vfik_handle* h) {
+    if (h->s_in) HIP_TRY(hipStreamSynchronize(h->s_in));
+    if (h->s_out) HIP_TRY(hipStreamSynchronize(h->s_out));
+    return VFIK_OK;
+}
+
+// true when the GPU can dereference p: device memory, or pinned / registered host memory
+bool gpu_visible(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
 template <typename T>
@@ -296,12 +325,20 @@ void vfik_destroy(vfik_handle* h) {
     void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
+    for (auto& ps : h->pipe) {
+        if (ps.ev_out) (void)hipEventSynchronize(ps.ev_out);
+        for (auto& s : ps.sc) if (s.p) (void)hipFree(s.p);
+        for (hipEvent_t e : {ps.ev_in, ps.ev_k, ps.ev_out}) if (e) (void)hipEventDestroy(e);
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
 int vfik_set_stream(vfik_handle* h, void* hip_stream) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) HIP_TRY(hipStreamDestroy(h->stream));
@@ -314,6 +351,7 @@ int vfik_set_stream(vfik_handle* h, void* hip_stream) {
 
 int vfik_set_chain(vfik_handle* h, const vfik_chain* c) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (!c) return fail(VFIK_E_ARG, "null chain");
     if (c->n != h->n) return fail(VFIK_E_ARG, "chain has %d joints, handle was created for %d", c->n, h->n);
     for (int i = 0; i < c->n; ++i) {
@@ -334,6 +372,7 @@ int vfik_set_chain(vfik_handle* h, const vfik_chain* c) {
 
 int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (!p) return fail(VFIK_E_ARG, "null params");
     if (!(p->lambda >= 0.0) || !(p->speed_scale >= 0.0) || !(p->max_vel >= 0.0) || !std::isfinite(p->lambda))
         return fail(VFIK_E_ARG, "lambda, speed_scale and max_vel must be finite and >= 0");
@@ -376,6 +415,7 @@ static int ensure_arm_weights(vfik_handle* h) {
 
 int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double* wy, const double* wq) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
     if (!wy && !wq) return fail(VFIK_E_ARG, "vfik_set_arm_weights: give wy, wq or both");
     for (int j = 0; j < n_arms; ++j) {
@@ -401,6 +441,7 @@ int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double
 
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (!tool16) return fail(VFIK_E_ARG, "null tool");
     HIP_TRY(hipSetDevice(h->device));
     if (!per_arm) {  // one sticky tool frame for the batch: lives with the other shared constants
@@ -426,6 +467,7 @@ int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {
 int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field* fields, int max_fields,
                     const int32_t* counts) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (!fields || !counts) return fail(VFIK_E_ARG, "null fields / counts");
     if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
     if (max_fields < 0) return fail(VFIK_E_ARG, "negative max_fields");
@@ -476,6 +518,7 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
 
 int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double* values) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (!values) return fail(VFIK_E_ARG, "null values");
     if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
     for (int j = 0; j < n_arms; ++j)
@@ -492,6 +535,7 @@ int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double
 
 int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     HIP_TRY(hipSetDevice(h->device));
     if (!w) {  // back to the batch-wide weights of vfik_params.mix_w
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -525,6 +569,7 @@ int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const doub
 
 int vfik_set_ext_cmd(vfik_handle* h, int channel, const void* cmd_host) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     if (channel < 2 || channel >= VFIK_MIX_CHANNELS) return fail(VFIK_E_ARG, "channel %d: only 2..%d are external", channel, VFIK_MIX_CHANNELS - 1);
     HIP_TRY(hipSetDevice(h->device));
     const size_t chan = (size_t)h->B * h->n * h->esz;
@@ -541,6 +586,7 @@ int vfik_set_ext_cmd(vfik_handle* h, int channel, const void* cmd_host) {
 
 int vfik_reset_state(vfik_handle* h) {
     if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     HIP_TRY(hipSetDevice(h->device));
     std::vector<int> ones(h->B, 1);
     HIP_TRY(hipMemsetAsync(h->d_lastvec, 0, (size_t)h->n * h->B * sizeof(double), h->stream));
@@ -549,7 +595,7 @@ int vfik_reset_state(vfik_handle* h) {
     return VFIK_OK;
 }
 
-static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out) {
+static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out, hipStream_t stream) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
@@ -561,17 +607,17 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     a.dt = dt;
     a.clamp = clamp ? 1 : 0;
     a.q_out = q_out;
-    hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, h->stream);
+    hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, stream);
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VFIK_OK;
 }
 
-int vfik_step(vfik_handle* h, const vfik_io* io) { return launch_cycles(h, io, 0, 0.0, 0, nullptr); }
+int vfik_step(vfik_handle* h, const vfik_io* io) { return launch_cycles(h, io, 0, 0.0, 0, nullptr, h ? h->stream : nullptr); }
 
 int vfik_rollout(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out) {
     if (n_cycles < 1 || n_cycles > 1000000) return fail(VFIK_E_ARG, "n_cycles %d outside [1, 1e6]", n_cycles);
     if (!std::isfinite(dt)) return fail(VFIK_E_ARG, "dt must be finite");
-    return launch_cycles(h, io, n_cycles, dt, clamp_to_limits, q_out);
+    return launch_cycles(h, io, n_cycles, dt, clamp_to_limits, q_out, h ? h->stream : nullptr);
 }
 
 int vfik_sync(vfik_handle* h) {
@@ -630,6 +676,125 @@ int vfik_step_host(vfik_handle* h, const vfik_io* io) { return cycles_host(h, io
 int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out) {
     if (n_cycles < 1) return fail(VFIK_E_ARG, "n_cycles must be >= 1");
     return cycles_host(h, io, n_cycles, dt, clamp_to_limits, q_out);
+}
+
+// ---- pipelined host path -------------------------------------------------------------------------
+void* vfik_host_alloc(vfik_handle* h, size_t bytes) {
+    if (!h || bytes == 0) { fail(VFIK_E_ARG, "vfik_host_alloc: bad arguments"); return nullptr; }
+    void* p = nullptr;
+    if (hipSetDevice(h->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(VFIK_E_HIP, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+int vfik_host_free(vfik_handle* h, void* p) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipHostFree(p));
+    return VFIK_OK;
+}
+
+int vfik_wait(vfik_handle* h, long ticket) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (ticket < 0 || ticket >= h->next_ticket) return fail(VFIK_E_ARG, "vfik_wait: unknown ticket %ld", ticket);
+    auto& ps = h->pipe[ticket % vfik_handle::PIPE];
+    if (ps.ticket != ticket) return VFIK_OK;  // already waited for (or its slot was recycled, which waits)
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(ps.ev_out));
+    ps.ticket = -1;
+    return VFIK_OK;
+}
+
+int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!io || !io->q || !ticket) return fail(VFIK_E_ARG, "vfik_submit_host needs io->q and a ticket");
+    if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->s_in) {  // non-blocking: no implicit ordering against the NULL stream a caller may have chosen
+        HIP_TRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    }
+    auto& ps = h->pipe[h->next_ticket % vfik_handle::PIPE];
+    if (!ps.ev_in) {
+        HIP_TRY(hipEventCreateWithFlags(&ps.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ps.ev_k, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ps.ev_out, hipEventDisableTiming));
+    }
+    if (ps.ticket >= 0) {  // the slot's previous submission must have left the device before its buffers are reused
+        HIP_TRY(hipEventSynchronize(ps.ev_out));
+        ps.ticket = -1;
+    }
+    const size_t B = h->B, n = h->n, e = h->esz;
+    const void* hin[4] = {io->q, io->null_control, io->q_ref, io->q_cmded};
+    const size_t bin[4] = {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e};
+    void* hout[9] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, io->goal_dist};
+    const size_t bout[9] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * 2 * e};
+    auto need = [&](int i, size_t bytes) -> void* {
+        auto& sc = ps.sc[i];
+        if (sc.bytes < bytes) {
+            if (sc.p) (void)hipFree(sc.p);
+            sc.p = nullptr; sc.bytes = 0;
+            if (hipMalloc(&sc.p, bytes) != hipSuccess) return nullptr;
+            sc.bytes = bytes;
+        }
+        return sc.p;
+    };
+    // Zero-copy: when every buffer is pinned (device-visible) host memory the kernel reads q and writes
+    // qdot across PCIe itself -- no staging, one launch per submission.  Measured on C3 (1.8 MB each
+    // way): 66 us per step against 95 us for the three-stream staging below.
+    bool direct = true;
+    for (int i = 0; i < 4 && direct; ++i) direct = !hin[i] || gpu_visible(hin[i]);
+    for (int i = 0; i < 9 && direct; ++i) direct = !hout[i] || gpu_visible(hout[i]);
+    if (direct) {
+        static const bool hybrid = std::getenv("VFIK_HOST_HYBRID") != nullptr;
+        vfik_io d = *io;
+        if (hybrid) {  // experiment: inputs by the copy engine (overlaps the previous kernel), outputs written by the kernel
+            const void** din[4] = {&d.q, &d.null_control, &d.q_ref, &d.q_cmded};
+            for (int i = 0; i < 4; ++i)
+                if (hin[i]) {
+                    void* dp = need(i, bin[i]);
+                    if (!dp) return fail(VFIK_E_HIP, "staging allocation failed");
+                    HIP_TRY(hipMemcpyAsync(dp, hin[i], bin[i], hipMemcpyHostToDevice, h->s_in));
+                    *din[i] = dp;
+                }
+            HIP_TRY(hipEventRecord(ps.ev_in, h->s_in));
+            HIP_TRY(hipStreamWaitEvent(h->stream, ps.ev_in, 0));
+        }
+        const int rc = launch_cycles(h, &d, 0, 0.0, 0, nullptr, h->stream);
+        if (rc != VFIK_OK) return rc;
+        HIP_TRY(hipEventRecord(ps.ev_out, h->stream));
+        ps.ticket = h->next_ticket;
+        *ticket = h->next_ticket++;
+        return VFIK_OK;
+    }
+    void* din[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dout[9];
+    for (int i = 0; i < 4; ++i)
+        if (hin[i] && !(din[i] = need(i, bin[i]))) return fail(VFIK_E_HIP, "staging allocation failed");
+    for (int i = 0; i < 9; ++i) {
+        dout[i] = hout[i] ? need(4 + i, bout[i]) : nullptr;
+        if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "staging allocation failed");
+    }
+    for (int i = 0; i < 4; ++i)
+        if (hin[i]) HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->s_in));
+    HIP_TRY(hipEventRecord(ps.ev_in, h->s_in));
+    HIP_TRY(hipStreamWaitEvent(h->stream, ps.ev_in, 0));
+    vfik_io d{};
+    d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
+    d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
+    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[8];
+    const int rc = vfik_step(h, &d);
+    if (rc != VFIK_OK) return rc;
+    HIP_TRY(hipEventRecord(ps.ev_k, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->s_out, ps.ev_k, 0));
+    for (int i = 0; i < 9; ++i)
+        if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->s_out));
+    HIP_TRY(hipEventRecord(ps.ev_out, h->s_out));
+    ps.ticket = h->next_ticket;
+    *ticket = h->next_ticket++;
+    return VFIK_OK;
 }
 
 int vfik_track_reset(vfik_handle* h) {

@@ -78,6 +78,10 @@ def load_library(path=None):
         "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "vfik_slots_in_use": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
+        "vfik_host_alloc": (C.c_void_p, [H, C.c_size_t]),
+        "vfik_host_free": (C.c_int, [H, C.c_void_p]),
+        "vfik_submit_host": (C.c_int, [H, C.POINTER(IO), C.POINTER(C.c_long)]),
+        "vfik_wait": (C.c_int, [H, C.c_long]),
         "vfik_set_arm_weights": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     }
@@ -122,6 +126,7 @@ class Engine:
         self.max_slots = int(max_slots)
         self.device = int(device)
         bits = 32 if self.io_dtype == np.float32 else 64
+        self._pinned = []
         self.h = self.lib.vfik_create(self.device, bits, self.n, self.max_slots, self.batch)
         if not self.h:
             raise VfikError("vfik_create: " + self.lib.vfik_last_error().decode())
@@ -137,6 +142,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            self.lib.vfik_sync(self.h)
+            for p in self._pinned:  # arrays handed out by host_array() die with the engine
+                self.lib.vfik_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.lib.vfik_destroy(self.h)
             self.h = None
 
@@ -244,6 +253,48 @@ class Engine:
             setattr(io, k, out[k].ctypes.data)
         self._chk(self.lib.vfik_step_host(self.h, C.byref(io)))
         return out
+
+    # -- pipelined host path (vfik_submit_host / vfik_wait) ------------------------------------------
+    def host_array(self, shape, dtype=None):
+        """A pinned host array (hipHostMalloc) that submit_host can copy from / to asynchronously.
+        Freed with the engine (close)."""
+        dtype = np.dtype(self.io_dtype if dtype is None else dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = self.lib.vfik_host_alloc(self.h, max(nbytes, 1))
+        if not p:
+            raise VfikError("vfik_host_alloc: " + self.lib.vfik_last_error().decode())
+        self._pinned.append(p)
+        buf = (C.c_char * max(nbytes, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def submit_host(self, q, outs, null_control=None, q_ref=None, q_cmded=None):
+        """Asynchronous vfik_step_host: ``q`` and the arrays of ``outs`` ({"qdot_out": array, ...}) must
+        be C-contiguous arrays of the engine's dtype (``status``: int32) that stay untouched until
+        :meth:`wait` -- use :meth:`host_array` for overlap.  Returns the ticket."""
+        io = IO()
+        for name, arr, cols in (("q", q, self.n), ("null_control", null_control, _abi.NULL_CONTROLS), ("q_ref", q_ref, self.n),
+                                ("q_cmded", q_cmded, self.n)):
+            if arr is None:
+                continue
+            self._check_host(name, arr, (self.batch, cols), self.io_dtype)
+            setattr(io, name, arr.ctypes.data)
+        for k, arr in outs.items():
+            if k == "status":
+                self._check_host(k, arr, (self.batch,), np.int32)
+            else:
+                self._check_host(k, arr, self._shape(k), self.io_dtype)
+            setattr(io, k, arr.ctypes.data)
+        t = C.c_long(-1)
+        self._chk(self.lib.vfik_submit_host(self.h, C.byref(io), C.byref(t)))
+        return int(t.value)
+
+    @staticmethod
+    def _check_host(name, arr, shape, dtype):
+        if not isinstance(arr, np.ndarray) or arr.shape != tuple(shape) or arr.dtype != np.dtype(dtype) or not arr.flags.c_contiguous:
+            raise ValueError("%s must be a C-contiguous %s array of shape %s" % (name, np.dtype(dtype).name, tuple(shape)))
+
+    def wait(self, ticket):
+        self._chk(self.lib.vfik_wait(self.h, int(ticket)))
 
     def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",), q_ref=None):
         """n_cycles control cycles in one launch with q integrated on the device.
