@@ -142,12 +142,12 @@ int vfik_sync(vfik_handle* h);
 /* Pipelined host path.  The reference's modules exchange Python lists over ports every cycle
  * (vf:312-315,462-466): for a host that keeps q and qdot in its own memory the copies, not the kernel,
  * bound the rate.  vfik_submit_host is vfik_step_host without the wait; outputs are in host memory after
- * vfik_wait(ticket); up to 3 submissions are in flight.  With PINNED buffers (vfik_host_alloc, or the
- * caller's own hipHostMalloc / hipHostRegister / torch pin_memory) the kernel reads q and writes qdot across
- * PCIe itself -- zero-copy, one launch per submission, alternating between two streams so that one step's
- * writes overlap the next step's reads (one stream, in order, when the nullspace module keeps per-arm state).
- * With pageable buffers copy-in, kernel and copy-out are staged on three streams.  The io buffers must
- * stay untouched until vfik_wait.  Device pointers are accepted as well (then it is vfik_step + an event). */
+ * vfik_wait(ticket); up to 3 submissions are in flight; kernels run in submission order on the handle's
+ * stream.  With PINNED buffers (vfik_host_alloc, or the caller's own hipHostMalloc / hipHostRegister / torch
+ * pin_memory) the kernel writes qdot across PCIe itself (zero-copy); q is read the same way when nothing
+ * else is in flight, and moved by the copy engine, overlapping the previous kernel, when something is.
+ * With pageable buffers copy-in, kernel and copy-out are staged on three streams.  The io buffers must stay
+ * untouched until vfik_wait.  Device pointers are accepted as well (then it is vfik_step + an event). */
 void* vfik_host_alloc(vfik_handle* h, size_t bytes);
 int vfik_host_free(vfik_handle* h, void* p);
 int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket);
