@@ -1,0 +1,106 @@
+"""Randomised differential test: 36 seeded configurations (chain, batch size, dtype, feature flags, field
+mix, tools, weights, speed scales, external channels) through the C-ABI against the CPU oracle.  Batch
+sizes straddle the wave size (1, 63, 64, 65, ...), field lists are ragged and include the general path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BATCHES = [1, 2, 63, 64, 65, 127, 129, 500, 1000]
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, engine, robots, synth
+    return dict(oc=oracle_c, abi=_abi, engine=engine, robots=robots, synth=synth)
+
+
+def _random_fields(abi, chain, B, rng, dt, general):
+    M = int(rng.integers(1, 9))
+    F = np.zeros((B, M), dtype=abi.FIELD_DTYPE)
+    n = np.zeros(B, dtype=np.int32)
+    order = float(rng.choice([2.0, 5.0, 20.0]))
+    for b in range(B):
+        cnt = int(rng.integers(0, M + 1))
+        for k in range(cnt):
+            f = F[b, k]
+            f["id"] = int(rng.integers(1, 60))
+            t = 1 if k == 0 and rng.random() < 0.85 else (int(rng.choice([1, 2, 4, 5, 0])) if general else 2)
+            f["type"] = t
+            if t == 1:
+                f["force"] = float(rng.uniform(0.5, 2.0))
+                f["p"][:16] = chain.fk(rng.uniform(0.8 * chain.q_lo, 0.8 * chain.q_hi))[0].reshape(16)
+                f["p"][16] = rng.uniform(0.02, 0.2)
+            elif t == 2:
+                f["force"] = -10.0
+                f["p"][:6] = [*rng.uniform(-0.8, 0.8, 2), rng.uniform(0, 1.2), rng.uniform(0.03, 0.1), 0.001,
+                              order if not general else float(rng.choice([2.0, 5.0, 3.5]))]
+            elif t == 4:
+                f["force"] = -50.0
+                f["p"][:8] = [*rng.uniform(-0.5, 0.5, 2), -0.5, *(rng.normal(size=2) * 0.1), 1.0, 0.05, 5.0]
+            elif t == 5:
+                f["force"] = 30.0
+                f["p"][:10] = [*rng.uniform(-0.6, 0.6, 3), *rng.normal(size=3), 0.15, 10.0, 0.15, 2.0]
+        n[b] = cnt
+    F["p"] = F["p"].astype(dt).astype(np.float64)  # inputs are rounded to the I/O type before both sides see them
+    F["force"] = F["force"].astype(dt).astype(np.float64)
+    return F, n
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_configuration(env, seed):
+    abi = env["abi"]
+    rng = np.random.default_rng(1000 + seed)
+    robot = ["lwr", "powercube6", "lwr_dual14", "lwr"][seed % 4]
+    chain = env["robots"].by_name(robot)
+    n = chain.n
+    B = BATCHES[seed % len(BATCHES)]
+    dt = np.float32 if seed % 3 == 2 else np.float64
+    flags = int(rng.choice([0, abi.F_MIXER, abi.F_NULLSPACE | abi.F_MIXER, abi.F_NULLSPACE | abi.F_MIXER | abi.F_LIMITER,
+                            abi.F_NULLSPACE | abi.F_JOINT_LIMIT_TASK | abi.F_MIXER, abi.F_LIMITER]))
+    general = bool(seed % 2)
+    F, nf = _random_fields(abi, chain, B, rng, dt, general)
+    q = rng.uniform(0.9 * chain.q_lo, 0.9 * chain.q_hi, (B, n)).astype(dt).astype(np.float64)
+    kw = dict(flags=flags, speed_scale=float(rng.uniform(0.05, 1.0)), max_vel=float(rng.uniform(0.2, 2.0)),
+              mix_w=list(rng.uniform(0, 1, 6).round(3)))
+    unit_w = rng.random() < 0.5
+    if not unit_w:
+        kw["wy"] = list(rng.uniform(0.1, 1.0, 6))
+        kw["wq"] = list(rng.uniform(0.1, 1.0, n)) + [1.0] * (16 - n)
+    params = abi.default_params(**kw)
+    tool = None
+    if rng.random() < 0.5:
+        tool = np.eye(4)
+        c, s = np.cos(0.4), np.sin(0.4)
+        tool[:3, :3] = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+        tool[:3, 3] = rng.uniform(-0.2, 0.2, 3)
+        tool = tool.reshape(16)
+    ctrl = None
+    if flags & abi.F_NULLSPACE and n - 6 == 1:
+        ctrl = rng.uniform(-1, 1, (B, 4)).astype(dt).astype(np.float64)
+    ext = None
+    if flags & abi.F_MIXER and rng.random() < 0.5:
+        ext = rng.uniform(-1, 1, (4, B, n)).astype(dt).astype(np.float64)
+
+    eng = env["engine"].Engine(chain, B, io_dtype=dt, max_slots=3 * F.shape[1], params=params)
+    eng.set_fields(F, nf)
+    if tool is not None:
+        eng.set_tool(tool)
+    if ext is not None:
+        for ch in range(4):
+            eng.set_ext_cmd(2 + ch, ext[ch])
+    want = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status")
+    got = eng.step_host(q, null_control=ctrl, want=want)
+    ref = env["oc"].cycle_batch(chain, params, q, F, nf, tool=tool, null_control=ctrl, ext_cmd=ext)
+    tol = 1e-9 if dt == np.float64 else 2e-5
+    for k in want:
+        if k == "status":
+            assert np.array_equal(got[k], ref[k]), (seed, np.nonzero(got[k] != ref[k])[0][:5])
+        else:
+            assert np.isfinite(got[k]).all(), (seed, k)
+            err = np.abs(got[k].astype(np.float64) - ref[k]).max()
+            assert err < tol, (seed, robot, B, k, err)
+    eng.close()
