@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     const long Bs = a.B;
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
-    const KcPtr kc = (KcPtr)(unsigned long long)a.kc;
+    const KcPtr kc_launch = (KcPtr)(unsigned long long)a.kc;
     int status = 0;
     STAMP(0);
 
@@ -517,7 +517,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
     double lv_r[NJ];
-    if constexpr (NULLSP && ROLL) {  // (a single-cycle launch reads the state where it is used: fewer live registers)
+    if constexpr (NULLSP && ROLL && NJ <= 7) {  // (a single-cycle launch reads the state where it is used: fewer live
+        // registers; chains of 8+ joints have nullity >= 2 and never use the sign memory)
         sig_r = a.sig[arm];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
@@ -528,9 +529,11 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // cycle-invariant reads (constants, goal, slots: ~200 doubles) out of the cycle loop and spills.
     const KConst<NJ>* klc = kl;
     int lanec = lane;
+    KcPtr kc = kc_launch;
     if (ROLL && NJ >= 10) {  // long chains have no registers to spare for cycle-invariant copies of the inputs
         asm volatile("" : "+v"(klc));
         asm volatile("" : "+v"(lanec));
+        asm volatile("" : "+s"(kc));  // nor SGPRs for ~70 hoisted scalar constants (they would spill through VGPR lanes)
     }
     const bool first = !ROLL || cyc == 0;
     if (ROLL && !first && a.slots_used > PRE) {  // the rows hold the last chunk of the previous cycle
@@ -1216,7 +1219,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         }
     }
     }  // cycles of this launch
-    if constexpr (NULLSP && ROLL) {
+    if constexpr (NULLSP && ROLL && NJ <= 7) {
         a.sig[arm] = sig_r;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
