@@ -160,6 +160,8 @@ int vfik_wait(vfik_handle* h, long ticket);
  * configuration; the outputs named in io are those of the LAST cycle; q_out[B][n] (may be NULL) receives
  * the joint angles after it.  Field sets, tools, weights and /control stay fixed during the launch,
  * as they do between two messages in the reference; the nullspace sign memory advances every cycle.
+ * Chains of up to 7 joints run all cycles inside one kernel; longer chains (no registers left for
+ * loop-carried state) run n_cycles single-cycle launches that integrate q on the way out -- same results.
  * Device pointers, asynchronous; vfik_rollout_host takes host pointers and synchronises. */
 int vfik_rollout(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);
 int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp_to_limits, void* q_out);

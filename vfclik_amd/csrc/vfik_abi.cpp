@@ -68,6 +68,7 @@ struct vfik_handle {
     int* d_sig = nullptr;      // [B]
     double* d_mixw = nullptr;  // [16]
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    void* d_rollq[2] = {nullptr, nullptr};  // q ping-pong of the stepped rollout (long chains)
     double* d_wts = nullptr;    // per-arm IK weights [6 + n][Bpad], allocated by vfik_set_arm_weights
     double* d_track = nullptr;  // tracking-error history [38][B], allocated on first use
     void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
@@ -322,7 +323,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     for (auto& ps : h->pipe) {
@@ -603,9 +604,35 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     HIP_TRY(hipSetDevice(h->device));
     vfik::KArgs a;
     fill_kargs(h, io, a);
-    a.n_cycles = n_cycles;
     a.dt = dt;
     a.clamp = clamp ? 1 : 0;
+    if (n_cycles > 0 && h->n > VFIK_ROLL_MAX_NJ) {
+        // Long chains: the rollout is n_cycles single-cycle launches, each integrating q on its way out
+        // (q ping-pongs between two device buffers; the caller's io->q is never written).  The kernel has
+        // no registers left for loop-carried state at these sizes -- the in-kernel loop spills and is
+        // slower than this (C5: 22 us per cycle against 17.4 us).  Outputs are those of the last cycle,
+        // status bits accumulate, the nullspace state advances launch by launch.
+        const size_t qbytes = (size_t)h->B * h->n * h->esz;
+        for (int k = 0; k < 2; ++k)
+            if (!h->d_rollq[k] && dev_alloc(h, &h->d_rollq[k], qbytes, false)) return VFIK_E_HIP;
+        a.n_cycles = 0;
+        const void* q_in = io->q;
+        for (int c = 0; c < n_cycles; ++c) {
+            const bool last = c == n_cycles - 1;
+            vfik::KArgs k = a;
+            k.q = q_in;
+            k.q_out = (last && q_out) ? q_out : h->d_rollq[c & 1];
+            k.status_or = c > 0;
+            if (!last) {  // intermediate cycles produce no outputs but the status bits
+                k.qdot_vf = k.qdot_null = k.qdot_out = k.pose = k.pose_nt = k.v6 = k.qdist = k.goal_dist = nullptr;
+            }
+            hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, k, h->block, stream);
+            if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+            q_in = k.q_out;
+        }
+        return VFIK_OK;
+    }
+    a.n_cycles = n_cycles;
     a.q_out = q_out;
     hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, stream);
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));

@@ -62,6 +62,10 @@ struct KConst {
     static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
 
+// Chains longer than this have no registers left for loop-carried state: their rollout is a sequence of
+// single-cycle launches that integrate q on the way out (vfik_abi.cpp), not the ROLL kernel variant.
+#define VFIK_ROLL_MAX_NJ 7
+
 struct KArgs {
     int B;
     int Bpad;         // B rounded up to 64: pitch of the quad planes
@@ -100,6 +104,7 @@ struct KArgs {
     double dt;
     int n_cycles;                // 0: ordinary single-cycle launch
     int clamp;                   // keep q inside [q_lo, q_hi] after each integration step
+    int status_or;               // OR the status bits into what a.status already holds (cycle 2.. of a stepped rollout)
 };
 
 // size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest

@@ -1211,7 +1211,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             o[1] = (T)(gdist[1] * 57.295779513082320877);
         }
     }
-    if (ROLL) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
+    if (ROLL || a.q_out) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             q[i] = __builtin_fma(a.dt, qo[i], q[i]);
@@ -1224,12 +1224,12 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
     }
-    if (ROLL && a.q_out) {
+    if (a.q_out) {
         T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) o[i] = (T)q[i];
     }
-    if (a.status) a.status[arm] = status;
+    if (a.status) a.status[arm] = a.status_or ? (a.status[arm] | status) : status;
     STAMP(7);
 }
 
@@ -1351,8 +1351,13 @@ __global__ void __launch_bounds__(256) monitor_kernel(const T* pose, const T* fr
 
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
-    if (a.n_cycles > 0) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true>), grid, blk, lds, stream, a);
-    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false>), grid, blk, lds, stream, a);
+    if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
+        if (a.n_cycles > 0) {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true>), grid, blk, lds, stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false>), grid, blk, lds, stream, a);
 }
 
 template <typename T, int NJ>
