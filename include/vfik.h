@@ -174,6 +174,11 @@ int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt
 int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out);
 int vfik_track_reset(vfik_handle* h);
 
+/* Field probe of scripts/vf (vf:469-503, /pose_in -> /vector_out, "for visualizing"): every arm's field set
+ * evaluated at a pose handed in instead of the arm's forward kinematics; device pose[B][16] -> device
+ * v6[B][6] = speedScale * scalars * normCart(sum) (vf:491-494).  Asynchronous on the handle's stream. */
+int vfik_probe_field(vfik_handle* h, const void* pose, void* v6);
+
 /* Distance monitor of scripts/monitor_distance (monitor_distance:76-84,148-167) for the batch: device
  * pose[B][16] (what vfik_step wrote to io->pose), device frames[B][max_objects][16] (the object frames of
  * /dmonitor/objectsIn, object_feeder:215-227,306-315; unused slots may hold anything finite), device

@@ -84,6 +84,21 @@ def mix(cmd, w):
     return out
 
 
+def probe_field(params, fields, nfields, poses, speed=None):
+    """vf:469-503: speedScale * scalars * normCart(sum) of every arm's field set at the given poses (B,16)."""
+    fields = np.ascontiguousarray(fields, dtype=_abi.FIELD_DTYPE)
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    B, M = fields.shape
+    out = np.zeros((B, 6))
+    vec6, sc = np.zeros(6), np.zeros(2)
+    for b in range(B):
+        lib().vfo_field_eval(_p(fields[b]), C.c_int(int(nfields[b])), _p(poses[b, :12].copy()), C.c_double(params.rot_slowdown), _p(vec6), _p(sc))
+        s = params.speed_scale if speed is None else speed[b]
+        out[b, :3] = s * sc[0] * vec6[:3]
+        out[b, 3:] = s * sc[1] * vec6[3:]
+    return out
+
+
 def joint_p(ref, q, lo, hi, kp, delta):
     """(B,n) references and angles -> (kp*(clamp(ref)-q), at_goal flags)."""
     ref = np.ascontiguousarray(ref, dtype=np.float64)

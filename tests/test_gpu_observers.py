@@ -92,3 +92,42 @@ def test_object_distances_match_the_monitor(dt, tol):
     for p in (d_pose, d_fr, d_out):
         eng.dev_free(p)
     eng.close()
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-9), (np.float32, 2e-5)])
+def test_field_probe_at_arbitrary_poses(dt, tol):
+    """vfik_probe_field (vf:469-503): each arm's field set -- every primitive type, ragged -- at poses that are
+    NOT the arm's forward kinematics, against the oracle's field evaluation; per-arm speed scales apply."""
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, engine, robots, synth
+    chain = robots.lwr()
+    B = 200
+    rng = np.random.default_rng(31)
+    w = synth.make_workload(chain, B, 3, seed=31, io_dtype=dt, max_fields=6)
+    F = w["fields"]
+    for b in range(0, B, 3):  # add a hemisphere and a funnel to every third arm
+        F[b, 4]["id"], F[b, 4]["type"], F[b, 4]["force"] = 30, 4, -50.0
+        F[b, 4]["p"][:8] = [0.2, -0.1, -0.5, 0.05, -0.02, 1.0, 0.05, 5.0]
+        F[b, 5]["id"], F[b, 5]["type"], F[b, 5]["force"] = 2, 5, 30.0
+        F[b, 5]["p"][:10] = [0.3, 0.2, 0.5, 0.1, 0.2, -0.9, 0.15, 10.0, 0.15, 2.0]
+        w["nfields"][b] = 6
+    F["p"] = F["p"].astype(dt).astype(np.float64)
+    params = _abi.default_params(rot_slowdown=0.2)
+    eng = engine.Engine(chain, B, io_dtype=dt, max_slots=12, params=params)
+    eng.set_fields(F, w["nfields"])
+    speed = rng.uniform(0.05, 0.41, B)
+    eng.set_speed_scale(speed)
+    poses = chain.fk(rng.uniform(chain.q_lo, chain.q_hi, (B, 7))).reshape(B, 16).astype(dt)
+    esz = np.dtype(dt).itemsize
+    d_pose, d_v6 = eng.dev_alloc(B * 16 * esz), eng.dev_alloc(B * 6 * esz)
+    eng.h2d(d_pose, poses)
+    eng.probe_field(d_pose, d_v6)
+    got = np.zeros((B, 6), dtype=dt)
+    eng.d2h(got, d_v6)
+    ref = oracle_c.probe_field(params, F, w["nfields"], poses.astype(np.float64), speed=speed)
+    assert np.abs(got - ref).max() < tol
+    assert np.abs(got).max() > 0.01
+    eng.dev_free(d_pose); eng.dev_free(d_v6)
+    eng.close()

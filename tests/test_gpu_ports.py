@@ -307,3 +307,53 @@ def test_weight_port_sets_the_weights_of_that_arm_only(net):
     cc.close()
     for f in feeders:
         f.close()
+
+
+def test_pose_in_probe_and_goal_out(net):
+    """/pose_in -> /vector_out (vf:469-503) and /goal_out on every 21st cycle (vf:432-453)."""
+    yarp = net
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots
+    from vfclik_amd.handlers import HandleArmNew
+    from vfclik_amd.object_feeder import ObjectFeeder
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    base = "/0/lwr/right"
+    cc = ControlCycleBatch(chain, [base, "/0/lwr/left"], io_dtype=np.float64)
+    feeder = ObjectFeeder(base)
+    arm = HandleArmNew(arm="/right")
+    rng = np.random.default_rng(17)
+    goal = chain.fk(rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, 7))[0].reshape(16)
+    arm.go_cart([float(x) for x in goal])
+    feeder.spin_once()
+    probe_in, probe_out, goal_out = _open(yarp, "/viz/pose"), _open(yarp, "/viz/vector"), _open(yarp, "/viz/goal")
+    enc = _open(yarp, "/sim/encoders")
+    yarp.Network.connect("/viz/pose", base + "/vectorField/pose_in")
+    yarp.Network.connect(base + "/vectorField/vector_out", "/viz/vector")
+    yarp.Network.connect(base + "/vectorField/goal_out", "/viz/goal")
+    yarp.Network.connect("/sim/encoders", base + "/vectorField/qIn")
+    pose = chain.fk(rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, 7))[0].reshape(16)
+    _send(probe_in, pose)
+    assert not cc.cycle().any()          # no joint angles: no control cycle, but the probe answers
+    got = _read(probe_out)
+    F = np.zeros((1, 1), dtype=_abi.FIELD_DTYPE)
+    F[0, 0]["id"], F[0, 0]["type"], F[0, 0]["force"] = 1, 1, 1.0
+    F[0, 0]["p"][:16] = goal
+    F[0, 0]["p"][16] = 0.1
+    ref = oracle_c.probe_field(cc.params, F, np.ones(1, dtype=np.int32), pose[None])
+    assert got is not None and np.abs(got - ref[0]).max() < 1e-9
+    _send(probe_in, pose[:12])            # wrong size: ignored (vf:470)
+    cc.cycle()
+    assert _read(probe_out) is None
+    q = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, 7)
+    seen_goal = None
+    for k in range(22):                   # the 21st cycle reports vector and goal
+        _send(enc, q)
+        cc.cycle()
+        g = _read(goal_out)
+        if g is not None:
+            seen_goal = (k, g)
+    assert seen_goal is not None and seen_goal[0] == 20
+    assert np.abs(seen_goal[1][:16] - goal).max() == 0.0 and seen_goal[1][16] == 0.1
+    cc.close()
+    feeder.close()

@@ -846,6 +846,17 @@ int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out
     return VFIK_OK;
 }
 
+int vfik_probe_field(vfik_handle* h, const void* pose, void* v6) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (!pose || !v6) return fail(VFIK_E_ARG, "vfik_probe_field: pose and v6 are required");
+    HIP_TRY(hipSetDevice(h->device));
+    const double rs = h->params.rot_slowdown;
+    const double cos_slow = rs > 0.0 && rs < 3.14159265358979323846 ? std::cos(rs) : -2.0;  // as kconst_fill
+    hipError_t e = vfik::launch_probe(h->io_dtype, pose, h->d_goal, h->d_slots, h->B, h->Bpad, h->slots_used, rs, cos_slow, v6, h->stream);
+    if (e != hipSuccess) return fail(VFIK_E_HIP, "probe launch: %s", hipGetErrorString(e));
+    return VFIK_OK;
+}
+
 int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, int max_objects, void* out) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!pose || !frames || !out) return fail(VFIK_E_ARG, "vfik_object_distances: pose, frames and out are required");

@@ -116,6 +116,8 @@ double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params
 // Type-erased launchers (implemented in vfik_kernel.hip).  kargs points to a KArgs<nj>.
 uint32_t supported_joints_mask();
 hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream);
+hipError_t launch_probe(int io_dtype, const void* pose, const void* goal, const void* slots, int B, long Bp, int slots_used,
+                        double rot_slow, double cos_slow, void* out, hipStream_t stream);
 hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream);
 hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, int B, hipStream_t stream);
 hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K, long count, long chan_stride,

@@ -1349,6 +1349,52 @@ __global__ void __launch_bounds__(256) monitor_kernel(const T* pose, const T* fr
     out[2 * t + 1] = (T)(atan2(sn, c) * 57.295779513082320877);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Field probe of scripts/vf (vf:469-503, "for visualizing"): the arm's total field evaluated at a pose that
+// is handed in (/pose_in) instead of the forward kinematics: v6 = speedScale * scalars * normCart(sum)
+// (vf:491-494 = vf:344-347 at another frame).  One thread per arm; goal block and slots are read straight
+// from the quad planes through the general per-slot path.  pose [B][16], out [B][6].
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal, const T* slots, int B, long Bp, int slots_used,
+                                                    double rot_slow, double cos_slow, T* out) {
+    const int arm = blockIdx.x * blockDim.x + threadIdx.x;
+    if (arm >= B) return;
+    double Rt[9], pt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rt[3 * r + c] = (double)pose[(long)arm * 16 + 4 * r + c];
+        pt[r] = (double)pose[(long)arm * 16 + 4 * r + 3];
+    }
+    const long Qp = Bp * 4;
+    double gq[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gq[k] = (double)goal[(long)(k >> 2) * Qp + (long)arm * 4 + (k & 3)];
+    double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
+    double GR[9], Gp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) GR[3 * r + c] = gq[4 * r + c];
+        Gp[r] = gq[4 * r + 3];
+    }
+    attractor(Rt, pt, GR, Gp, gq[13], gq[14], rot_slow, cos_slow, gq[12] != 0.0, tot, sc, nullptr);
+    const T* sq = slots + (long)arm * 4;
+    for (int m = 0; m < slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, rot_slow, cos_slow, tot, sc);
+    double nt, nti, nr, nri;
+    sqrt_rsqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2], nt, nti);
+    sqrt_rsqrt(tot[3] * tot[3] + tot[4] * tot[4] + tot[5] * tot[5], nr, nri);
+    const double speed = gq[15];
+    const double kt = nt > EPS_LEN ? speed * sc[0] * nti : 0.0;
+    const double kr = nr > EPS_LEN ? speed * sc[1] * nri : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[(long)arm * 6 + k] = (T)(tot[k] * kt);
+        out[(long)arm * 6 + 3 + k] = (T)(tot[3 + k] * kr);
+    }
+}
+
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
@@ -1556,6 +1602,19 @@ hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K
 }  // namespace vfik
 
 namespace vfik {
+hipError_t launch_probe(int io_dtype, const void* pose, const void* goal, const void* slots, int B, long Bp, int slots_used,
+                        double rot_slow, double cos_slow, void* out, hipStream_t stream) {
+    const int block = 64;
+    const dim3 grid((B + block - 1) / block), blk(block);
+    if (io_dtype == 32)
+        hipLaunchKernelGGL(probe_kernel<float>, grid, blk, 0, stream, static_cast<const float*>(pose), static_cast<const float*>(goal),
+                           static_cast<const float*>(slots), B, Bp, slots_used, rot_slow, cos_slow, static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(probe_kernel<double>, grid, blk, 0, stream, static_cast<const double*>(pose), static_cast<const double*>(goal),
+                           static_cast<const double*>(slots), B, Bp, slots_used, rot_slow, cos_slow, static_cast<double*>(out));
+    return hipGetLastError();
+}
+
 hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream) {
     const int block = 256;
     const dim3 grid((unsigned)((count + block - 1) / block)), blk(block);

@@ -83,6 +83,7 @@ def load_library(path=None):
         "vfik_submit_host": (C.c_int, [H, C.POINTER(IO), C.POINTER(C.c_long)]),
         "vfik_wait": (C.c_int, [H, C.c_long]),
         "vfik_set_arm_weights": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+        "vfik_probe_field": (C.c_int, [H, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     }
     for name, (res, args) in protos.items():
@@ -384,6 +385,10 @@ class Engine:
         self._chk(self.lib.vfik_set_arm_weights(self.h, int(first_arm), counts.pop(),
                                                 None if arrs[0] is None else arrs[0].ctypes.data,
                                                 None if arrs[1] is None else arrs[1].ctypes.data))
+
+    def probe_field(self, pose_dev, v6_dev):
+        """The field of every arm at a given pose (vf:469-503): device pose[B][16] -> v6[B][6]."""
+        self._chk(self.lib.vfik_probe_field(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(v6_dev))))
 
     def object_distances(self, pose_dev, frames_dev, max_objects, out_dev):
         """Distance monitor (monitor_distance:148-167) on device arrays: out[B][max_objects][2]."""

@@ -112,6 +112,7 @@ class ControlCycleBatch:
         self._ext_dirty = [False] * 4
         self.objects = [dict() for _ in range(self.B)]   # monitor_distance:72: id -> frame16, insertion-ordered
         self._mon_bufs = None
+        self._probe_bufs = None
         self.q_ref = np.zeros((self.B, self.n))          # /jpctrl/ref (joint_p_controller:113-118)
         self.has_ref = np.zeros(self.B, dtype=bool)      # no reference yet: the controller commands nothing
         self.report_counter = 0  # vf:185,432-435
@@ -136,7 +137,7 @@ class ControlCycleBatch:
                 "qIn": mk(vf + "/qIn"), "qdotOut": mk(vf + "/qdotOut"), "param": mk(vf + "/param", True),
                 "tool": mk(vf + "/tool", True), "weight": mk(vf + "/weight", True), "max_vel": mk(vf + "/max_vel", True),
                 "pose": mk(vf + "/pose"), "pose_no_tool": mk(vf + "/pose_no_tool"), "pose_in": mk(vf + "/pose_in"),
-                "vector_out": mk(vf + "/vector_out"),
+                "vector_out": mk(vf + "/vector_out"), "goal_out": mk(vf + "/goal_out"),
                 "ns_qin": mk(ns + "/qin"), "ns_control": mk(ns + "/control"), "ns_qdotout": mk(ns + "/qdotout"),
                 "dbg_qin": mk(dbg + "/qin"), "qdist": mk(dbg + "/qdist"),
                 "encoders": mk(br + "/encoders"), "br_weight": mk(br + "/weight", True),
@@ -267,6 +268,7 @@ class ControlCycleBatch:
         got_q = self._poll()
         self._push_state()
         if not got_q.any():
+            self.probe()
             return got_q
         # the joint P controller feeds /bridge/jointcmd (joint_p_controller:78): once any arm has a
         # reference the fused controller owns mixer channel 2; arms without one get ref = q (zero command)
@@ -293,6 +295,8 @@ class ControlCycleBatch:
                 _send(d["jp_at_goal"], [], ints=[1 if out["status"][a] & _abi.ST_JOINT_AT_GOAL else 0])
             if report:
                 _send(d["vector_out"], out["v6"][a])         # vf:437-442
+                if 1 in self.fields.sets[a]:                  # vf:444-453: the goal's parameters
+                    _send(d["goal_out"], self.fields.sets[a][1][2])
             te = out["track_error"][a]
             if te.any():                                      # from the 6th frame on (vf:354,418-428)
                 _send(d["track_error"], te[:7], ints=[int(te[7])])
@@ -313,6 +317,7 @@ class ControlCycleBatch:
                         sb.addString(kind)
                         sb.addString(state)
                         d["tracking_state"].writeStrict()
+        self.probe()
         return got_q
 
     def _track_error(self, out):
@@ -328,6 +333,34 @@ class ControlCycleBatch:
         res = np.zeros((self.B, 8), dtype=e.io_dtype)
         e.d2h(res, d_out)
         return res.astype(np.float64)
+
+    def probe(self):
+        """The visualisation probe of scripts/vf (vf:469-503): for every arm with a 16-value bottle waiting on
+        /pose_in, the arm's field at that pose goes out on /vector_out.  Runs outside the control cycle, as
+        the reference's probe runs whether or not joint angles arrived."""
+        asked = {}
+        for a, d in enumerate(self.ports):
+            b = d["pose_in"].read(False)
+            if b is not None and b.size() == 16:
+                asked[a] = _bottle_doubles(b)
+        if not asked:
+            return asked
+        self._push_state()
+        e = self.engine
+        esz = e.io_dtype.itemsize
+        if self._probe_bufs is None:
+            self._probe_bufs = (e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * 6 * esz))
+        d_pose, d_v6 = self._probe_bufs
+        poses = np.tile(np.eye(4).reshape(16), (self.B, 1)).astype(e.io_dtype)
+        for a, p in asked.items():
+            poses[a] = p
+        e.h2d(d_pose, poses)
+        e.probe_field(d_pose, d_v6)
+        v6 = np.zeros((self.B, 6), dtype=e.io_dtype)
+        e.d2h(v6, d_v6)
+        for a in asked:
+            _send(self.ports[a]["vector_out"], v6[a])
+        return asked
 
     def _object_distances(self, out):
         """The distance monitor (monitor_distance:148-167) for the batch, on the device: [B][O][2] with the
