@@ -99,6 +99,11 @@ int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double
  * arm to the batch-wide vfik_params.mix_w. */
 int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w);
 
+/* Per-arm limiter speed: what each arm's bridge keeps after a /bridge/max_vel message (bridge:612-623; the
+ * reference accepts 0 <= v <= config.max_vel, the caller applies that rule).  Used with VFIK_F_LIMITER.  A
+ * vfik_set_params that CHANGES vfik_params.max_vel writes the new value to every arm. */
+int vfik_set_max_vel(vfik_handle* h, int first_arm, int n_arms, const double* values);
+
 /* Last command of mixer channel 2..5 (jointcmd, mechanismcmd, xtra1cmd, xtra2cmd; bridge:593-596)
  * for the whole batch: host array cmd[B][n] in the io dtype, or NULL to zero the channel, which is
  * also what the watchdog does after guard_time of silence (command_mixer.py:64-66). */

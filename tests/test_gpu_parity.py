@@ -360,6 +360,43 @@ def test_mixer_external_channels_and_limiter(env):
     assert ((got["status"] & f.ST_LIMITED) != 0).any()
 
 
+@pytest.mark.parametrize("dt,with_mixer", [(np.float64, True), (np.float32, True), (np.float64, False)])
+def test_limiter_speed_of_each_arm(env, dt, with_mixer):
+    """Every bridge keeps its own max_vel (bridge:612-623): groups of arms with different limiter speeds in
+    one batch, with and without per-arm mixer weights; a batch-wide change afterwards reaches every arm."""
+    chain = env.robots.lwr()
+    B = 192
+    f = env.abi
+    flags = f.F_LIMITER | (f.F_MIXER | f.F_NULLSPACE if with_mixer else 0)
+    w = env.synth.make_workload(chain, B, 2, seed=19, io_dtype=dt)
+    params = f.default_params(flags=flags, max_vel=0.5)
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=4, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    speeds = np.full(B, 0.5)
+    speeds[64:128] = 0.05
+    speeds[128:] = np.linspace(0.0, 0.3, 64)
+    eng.set_max_vel(speeds[64:], first_arm=64)
+    mixw = np.tile([1.0, 1.0, 0, 0, 0, 0], (B, 1))
+    if with_mixer:
+        mixw[::2, 1] = 0.3
+        eng.set_mixer_weights(mixw)  # must not disturb the limiter speeds stored beside the weights
+    got = eng.step_host(w["q"], want=("qdot_out", "status"))
+    tol = 1e-9 if dt == np.float64 else 2e-6
+    for b in (0, 1, 63, 64, 65, 127, 128, 129, 150, 191):
+        p = f.default_params(flags=flags, max_vel=float(np.float64(dt(speeds[b]))), mix_w=list(mixw[b]))
+        ref = env.oc.cycle_batch(chain, p, w["q"][b:b + 1], w["fields"][b:b + 1], w["nfields"][b:b + 1])
+        assert np.abs(got["qdot_out"][b] - ref["qdot_out"][0]).max() < tol, b
+        assert got["status"][b] == ref["status"][0], b
+    assert np.abs(got["qdot_out"]).max(axis=1)[64:128].max() <= 0.05 * (1 + 1e-6)
+    assert np.all(got["qdot_out"][128] == 0.0)  # max_vel 0: the arm stands still
+    eng.set_params(max_vel=0.02)
+    got = eng.step_host(w["q"], want=("qdot_out",))
+    assert np.abs(got["qdot_out"]).max() <= 0.02 * (1 + 1e-6)
+    with pytest.raises(env.engine.VfikError):
+        eng.set_max_vel([-0.1])
+    eng.close()
+
+
 def test_nan_is_flagged_not_fatal(env):
     chain = env.robots.lwr()
     f = env.abi

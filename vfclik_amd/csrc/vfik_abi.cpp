@@ -75,6 +75,7 @@ struct vfik_handle {
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
     size_t dev_bytes = 0;
     // host bookkeeping
+    std::vector<double> bridge_host;  // [B][8] mirror of d_mixw_arm: mixer weights 0..5, max_vel 6
     std::vector<int> slots_per_arm;
     std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
@@ -371,6 +372,8 @@ int vfik_set_chain(vfik_handle* h, const vfik_chain* c) {
     return rc;
 }
 
+static int upload_bridge_state(vfik_handle* h, int first_arm, int n_arms);
+
 int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
@@ -383,7 +386,14 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     bool weights_changed = false;
     for (int k = 0; k < 6; ++k) weights_changed = weights_changed || p->wy[k] != h->params.wy[k];
     for (int k = 0; k < h->n; ++k) weights_changed = weights_changed || p->wq[k] != h->params.wq[k];
+    const bool maxvel_changed = p->max_vel != h->params.max_vel;
     h->params = *p;
+    if (maxvel_changed && h->d_mixw_arm) {  // vfik_params.max_vel is batch-wide: written to every arm, like speed_scale
+        HIP_TRY(hipSetDevice(h->device));
+        for (int b = 0; b < h->B; ++b) h->bridge_host[(size_t)b * 8 + 6] = p->max_vel;
+        const int rc = upload_bridge_state(h, 0, h->B);
+        if (rc != VFIK_OK) return rc;
+    }
     if (weights_changed && h->d_wts) {  // new batch-wide IK weights replace every arm's own
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -534,38 +544,64 @@ int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double
     return VFIK_OK;
 }
 
-int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w) {
-    if (check_handle(h)) return VFIK_E_ARG;
-    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
-    HIP_TRY(hipSetDevice(h->device));
-    if (!w) {  // back to the batch-wide weights of vfik_params.mix_w
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->d_mixw_arm) { HIP_TRY(hipFree(h->d_mixw_arm)); h->d_mixw_arm = nullptr; }
-        return VFIK_OK;
+// Per-arm bridge state on the device: 2 quad planes [w0 w1 w2 w3 | w4 w5 max_vel -], mirrored on the host so
+// that the two setters below can rewrite an arm's quads without reading them back.
+static int upload_bridge_state(vfik_handle* h, int first_arm, int n_arms);
+static int ensure_bridge_state(vfik_handle* h) {
+    if (h->d_mixw_arm) return VFIK_OK;
+    const size_t plane = (size_t)h->Bpad * 4 * h->esz;
+    if (dev_alloc(h, &h->d_mixw_arm, 2 * plane, true)) return VFIK_E_HIP;
+    h->bridge_host.assign((size_t)h->B * 8, 0.0);
+    for (int b = 0; b < h->B; ++b) {  // every arm starts from the batch-wide values
+        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) h->bridge_host[(size_t)b * 8 + k] = h->params.mix_w[k];
+        h->bridge_host[(size_t)b * 8 + 6] = h->params.max_vel;
     }
-    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    return upload_bridge_state(h, 0, h->B);
+}
+
+static int upload_bridge_state(vfik_handle* h, int first_arm, int n_arms) {
     const size_t qb = 4 * h->esz, plane = (size_t)h->Bpad * qb;
-    if (!h->d_mixw_arm) {  // first use: every arm starts from the batch-wide weights
-        if (dev_alloc(h, &h->d_mixw_arm, 2 * plane, true)) return VFIK_E_HIP;
-        std::vector<char> all(2 * plane, 0);
-        for (int b = 0; b < h->B; ++b)
-            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) {
-                const size_t idx = ((size_t)(k >> 2) * h->Bpad + b) * 4 + (k & 3);
-                if (h->io_dtype == 32) put<float>(all, idx, h->params.mix_w[k]); else put<double>(all, idx, h->params.mix_w[k]);
-            }
-        HIP_TRY(hipMemcpyAsync(h->d_mixw_arm, all.data(), all.size(), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-    }
     std::vector<char> buf(2 * (size_t)n_arms * qb, 0);
     for (int j = 0; j < n_arms; ++j)
-        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const size_t idx = ((size_t)(k >> 2) * n_arms + j) * 4 + (k & 3);
-            if (h->io_dtype == 32) put<float>(buf, idx, w[j * VFIK_MIX_CHANNELS + k]); else put<double>(buf, idx, w[j * VFIK_MIX_CHANNELS + k]);
+            const double v = h->bridge_host[(size_t)(first_arm + j) * 8 + k];
+            if (h->io_dtype == 32) put<float>(buf, idx, v); else put<double>(buf, idx, v);
         }
     char* dst = static_cast<char*>(h->d_mixw_arm) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dst, plane, buf.data(), (size_t)n_arms * qb, (size_t)n_arms * qb, 2, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
+}
+
+int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
+    HIP_TRY(hipSetDevice(h->device));
+    if (!w) {  // back to the batch-wide values of vfik_params (mixer weights and limiter max_vel)
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_mixw_arm) { HIP_TRY(hipFree(h->d_mixw_arm)); h->d_mixw_arm = nullptr; }
+        h->bridge_host.clear();
+        return VFIK_OK;
+    }
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    if (ensure_bridge_state(h) != VFIK_OK) return VFIK_E_HIP;
+    for (int j = 0; j < n_arms; ++j)
+        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) h->bridge_host[(size_t)(first_arm + j) * 8 + k] = w[(size_t)j * VFIK_MIX_CHANNELS + k];
+    return upload_bridge_state(h, first_arm, n_arms);
+}
+
+int vfik_set_max_vel(vfik_handle* h, int first_arm, int n_arms, const double* values) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
+    if (!values) return fail(VFIK_E_ARG, "null values");
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    for (int j = 0; j < n_arms; ++j)
+        if (!(values[j] >= 0.0) || !std::isfinite(values[j])) return fail(VFIK_E_ARG, "arm %d: max_vel %g must be finite and >= 0", first_arm + j, values[j]);
+    HIP_TRY(hipSetDevice(h->device));
+    if (ensure_bridge_state(h) != VFIK_OK) return VFIK_E_HIP;
+    for (int j = 0; j < n_arms; ++j) h->bridge_host[(size_t)(first_arm + j) * 8 + 6] = values[j];
+    return upload_bridge_state(h, first_arm, n_arms);
 }
 
 int vfik_set_ext_cmd(vfik_handle* h, int channel, const void* cmd_host) {

@@ -1094,15 +1094,18 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
     double qo[NJ];
     bool direct = false;
-    if (a.flags & VFIK_F_MIXER) {
-        double mw[8];
+    double mw[8];  // this arm's bridge state: mixer weights 0..5, limiter max_vel 6 (per-arm quads, else the batch's)
+    if (a.flags & (VFIK_F_MIXER | VFIK_F_LIMITER)) {
         if (a.mixw) {
             read_quad<T>(region, Stage<T>::ROW_MIXW, lanec, mw);
             read_quad<T>(region, Stage<T>::ROW_MIXW + Q16, lanec, mw + 4);
         } else {
 #pragma unroll
             for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = kc->mix_w[k];
+            mw[6] = kc->max_vel;
         }
+    }
+    if (a.flags & VFIK_F_MIXER) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mac_unfused(0.0, qv[i], mw[0]), qn[i], mw[1]);
         if (a.q_ref) {  // joint P controller -> /bridge/jointcmd = channel 2 (joint_p_controller:78,89-99,124-128)
@@ -1139,8 +1142,8 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         double lead = 0.0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) lead = fmax(lead, fabs(qo[i]));
-        if (lead > kc->max_vel) {
-            const double ratio = kc->max_vel * rcp_nr(lead);
+        if (lead > mw[6]) {
+            const double ratio = mw[6] * rcp_nr(lead);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) qo[i] *= ratio;
             status |= VFIK_ST_LIMITED;

@@ -83,6 +83,7 @@ def load_library(path=None):
         "vfik_submit_host": (C.c_int, [H, C.POINTER(IO), C.POINTER(C.c_long)]),
         "vfik_wait": (C.c_int, [H, C.c_long]),
         "vfik_set_arm_weights": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+        "vfik_set_max_vel": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "vfik_probe_field": (C.c_int, [H, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     }
@@ -367,6 +368,11 @@ class Engine:
 
     def d2h(self, arr, src):
         self._chk(self.lib.vfik_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src), arr.nbytes))
+
+    def set_max_vel(self, values, first_arm=0):
+        """Per-arm limiter speed (the /bridge/max_vel value each bridge keeps, bridge:612-623)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        self._chk(self.lib.vfik_set_max_vel(self.h, int(first_arm), len(v), v.ctypes.data))
 
     def set_arm_weights(self, wy=None, wq=None, first_arm=0):
         """Per-arm IK weights (vf:295-309): wy (n_arms, 6) and/or wq (n_arms, n) starting at first_arm."""

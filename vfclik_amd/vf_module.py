@@ -100,6 +100,7 @@ class ControlCycleBatch:
         self.fields = FieldSets(self.B, max_fields)
         self.clock = clock
         self.guard_time = guard_time
+        self.config_max_vel = float(self.params.max_vel)  # bridge:608: config.max_vel bounds the runtime value
         self.speed = np.full(self.B, float(self.params.speed_scale))
         self.tools = np.tile(np.eye(4).reshape(16), (self.B, 1))  # vf:154
         self._tools_dirty = False
@@ -140,7 +141,7 @@ class ControlCycleBatch:
                 "vector_out": mk(vf + "/vector_out"), "goal_out": mk(vf + "/goal_out"),
                 "ns_qin": mk(ns + "/qin"), "ns_control": mk(ns + "/control"), "ns_qdotout": mk(ns + "/qdotout"),
                 "dbg_qin": mk(dbg + "/qin"), "qdist": mk(dbg + "/qdist"),
-                "encoders": mk(br + "/encoders"), "br_weight": mk(br + "/weight", True),
+                "encoders": mk(br + "/encoders"), "br_weight": mk(br + "/weight", True), "br_max_vel": mk(br + "/max_vel", True),
                 "current_weights": mk(br + "/current_weights"), "mixed": mk(br + "/mixed"),
                 "track_error": mk(vf + "/track_error"), "distOut": mk(base + "/dmonitor/distOut"),
                 "tracking_state": mk(base + "/dmonitor/tracking_state"),
@@ -195,6 +196,12 @@ class ControlCycleBatch:
                 for i in range(min(b.size(), _abi.MIX_CHANNELS)):
                     self.mix_w[a, i] = b.get(i).asDouble()
                 self._mix_dirty = True
+            for b in self._drain(d["br_max_vel"]):  # bridge:612-623: the limiter's joint speed
+                v = b.get(0).asDouble()
+                if 0.0 <= v <= self.config_max_vel:
+                    self.engine.set_max_vel([v], first_arm=a)
+                else:
+                    log.warning("arm %d: value of max_vel not between 0.0 and config.max_vel, ignoring", a)
             for ch, name in enumerate(MIX_PORTS[2:]):  # command_mixer.py:56-69
                 b = d[name].read(False)
                 if b and b.size() == self.n:
