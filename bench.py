@@ -74,8 +74,8 @@ def numpy_loop_rate(chain, params, w, arms=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
@@ -138,6 +138,7 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         eng.step(io)
+    enqueue_s = time.perf_counter() - t0  # host time to issue the launches (must stay below the kernel time)
     ev1.record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -239,7 +240,8 @@ def main():
             "config": {"workload": "%s: batch=%d/GPU x %d-DOF %s, goal + %d decay repellers, %s I/O, flags=0x%x"
                                    % (args.workload, B, chain.n, chain.name, nobs, io_name, flags),
                        "parallelism": "arm batch sharded over %d GPU(s), no collective" % world,
-                       "lambda": params.lambda_, "launches_per_step": 1},
+                       "lambda": params.lambda_, "launches_per_step": 1,
+                       "host_enqueue_us_per_step": enqueue_s * 1e6 / args.steps},
             "max_abs_err_rad_s": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
