@@ -46,3 +46,20 @@ span = int(st[:, 7].max() - st[:, 0].min())
 print("  first start -> last end: %d ticks; wave start spread %d ticks" % (span, int(st[:, 0].max() - st[:, 0].min())))
 ms = eng.time_steps(ioo, 5, 50)
 print("  diagnostic build: %.2f us per launch (do not quote)" % (ms * 1e3 / 50))
+# when do the waves start and end (10 ns resolution), and does it follow the workgroup index?
+s0 = (st[:, 8].astype(np.int64) - int(st[:, 8].min())) / 100.0
+e0 = (st[:, 9].astype(np.int64) - int(st[:, 8].min())) / 100.0
+print("  wave START after the first wave [us]: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(s0, [10, 50, 90, 100])))
+print("  wave END   after the first wave [us]: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(e0, [10, 50, 90, 100])))
+idx = np.arange(nw)
+print("  start vs workgroup index: corr %.2f; mean start of workgroups 0-127 %.2f, 448-575 %.2f, 896-1023 %.2f us"
+      % (np.corrcoef(idx, s0)[0, 1], s0[:128].mean(), s0[448:576].mean(), s0[896:].mean()))
+print("  mean start by (workgroup index mod 8): " + " ".join("%.2f" % s0[k::8].mean() for k in range(8)))
+# the slowest waves: which phase is long, and where do they sit?
+order = np.argsort(-tot)[:12]
+print("  slowest waves (index, xcd = index mod 8, total ticks, phase ticks):")
+for i in order:
+    print("    %5d  xcd %d  %6d  %s" % (i, i % 8, tot[i], " ".join("%5d" % x for x in d[i])))
+print("  p99 %d  p99.9 %d  max %d ticks; waves above median + 10%%: %d" % (np.percentile(tot, 99), np.percentile(tot, 99.9), tot.max(), int((tot > 1.1 * np.median(tot)).sum())))
+late = np.argsort(-e0)[:12]
+print("  last waves to end (index, start us, end us, duration ticks): " + "; ".join("%d %.2f %.2f %d" % (i, s0[i], e0[i], tot[i]) for i in late))

@@ -199,6 +199,29 @@ __device__ __forceinline__ double pow_order(double x, double order) {
     return isint ? powi_uniform(x, n) : pow(x, order);
 }
 
+// atan2(y, x) for y >= 0 (an angle in [0, pi]), branch-free: two reductions bring the argument of the
+// arctangent below tan(pi/8), where fdlibm's 11-coefficient kernel (s_atan.c, |x| < 7/16) is good to < 1 ulp.
+// ocml's atan2 costs a lone wave ~2 000 cycles (tools/stamps.py: the waves that needed it ended the kernel
+// 0.4 us after the rest); this is ~45 instructions.
+__device__ __forceinline__ double atan2_pos(double y, double x) {
+    const double ax = fabs(x);
+    const bool steep = y > ax;                         // angle from the nearer axis: t in [0, 1]
+    const double num = steep ? ax : y, den = steep ? y : ax;
+    double t = den > 0.0 ? num * rcp_nr(den) : 0.0;    // atan2(0, 0) = 0
+    const bool upper = t > 0.41421356237309503;        // tan(pi/8): atan(t) = pi/4 + atan((t - 1) / (t + 1))
+    const double tr = (t - 1.0) * rcp_nr(t + 1.0);
+    t = upper ? tr : t;
+    const double z = t * t, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    double a = t - t * (s1 + s2);
+    a = upper ? 0.78539816339744830962 + a : a;        // angle from the nearer axis, in [0, pi/4]
+    a = steep ? 1.57079632679489661923 - a : a;        // angle from the x axis of (|x|, y)
+    return x < 0.0 ? 3.14159265358979323846 - a : a;
+}
+
 // Unit rotation axis (base frame) and angle of the rotation taking R to G, i.e. of log(G R^T) =
 // KDL diff(R, G).rot.  Branch-free main line; the half-turn neighbourhood (sin(theta) < 1e-4, cos < 0),
 // where the antisymmetric part vanishes, is fixed up from the symmetric part under a wave-uniform
@@ -218,31 +241,26 @@ __device__ __forceinline__ void rot_axis_angle(const double* R, const double* G,
     axis[0] = a0 * sinv; axis[1] = a1 * sinv; axis[2] = a2 * sinv;
     has_axis = s >= EPS_LEN;
     theta = 3.14159265358979323846;
-    if (__any(c > cos_slow)) theta = atan2(s, c);  // some lane is within the slow-down angle
+    if (__any(c > cos_slow)) theta = atan2_pos(s, c);  // some lane is within the slow-down angle
     const bool half_turn = s < 1e-4 && c < 0.0;
     if (__any(half_turn)) {
-        // theta near pi (rare): axis from the symmetric part  c I + (1-c) a a^T
-        const double omc = 1.0 - c;
-        double x, y, z;
-        if (E[0] >= E[4] && E[0] >= E[8]) {
-            x = sqrt(fmax((E[0] - c) / omc, 0.0));
-            y = 0.5 * (E[3] + E[1]) / (omc * x);
-            z = 0.5 * (E[6] + E[2]) / (omc * x);
-        } else if (E[4] >= E[8]) {
-            y = sqrt(fmax((E[4] - c) / omc, 0.0));
-            x = 0.5 * (E[1] + E[3]) / (omc * y);
-            z = 0.5 * (E[7] + E[5]) / (omc * y);
-        } else {
-            z = sqrt(fmax((E[8] - c) / omc, 0.0));
-            x = 0.5 * (E[2] + E[6]) / (omc * z);
-            y = 0.5 * (E[5] + E[7]) / (omc * z);
-        }
-        if (x * a0 + y * a1 + z * a2 < 0.0) { x = -x; y = -y; z = -z; }
-        const double k = 1.0 / sqrt(x * x + y * y + z * z);
+        // theta near pi (4 arms in 65 536 random goals): the axis comes from the symmetric part,
+        // (E + E^T)/2 - c I = (1 - c) a a^T, whose row with the largest diagonal element is parallel to a;
+        // the sign from the (small) antisymmetric part.  Selects, one rsqrt: the waves that get here
+        // used to end the kernel 0.3 us after the others through three divergent branches with divisions.
+        const bool k0 = E[0] >= E[4] && E[0] >= E[8], k1 = !k0 && E[4] >= E[8];
+        const double s01 = 0.5 * (E[1] + E[3]), s02 = 0.5 * (E[2] + E[6]), s12 = 0.5 * (E[5] + E[7]);
+        double x = k0 ? E[0] - c : (k1 ? s01 : s02);
+        double y = k0 ? s01 : (k1 ? E[4] - c : s12);
+        double z = k0 ? s02 : (k1 ? s12 : E[8] - c);
+        const double flip = (x * a0 + y * a1 + z * a2 < 0.0) ? -1.0 : 1.0;
+        double nn, k;
+        sqrt_rsqrt(x * x + y * y + z * z, nn, k);
+        k *= flip;
         if (half_turn) {
             axis[0] = x * k; axis[1] = y * k; axis[2] = z * k;
             has_axis = true;
-            theta = atan2(s, c);
+            theta = atan2_pos(s, c);
         }
     }
 }
@@ -320,7 +338,7 @@ __device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const do
             sqrt_rsqrt(wx * wx + wy * wy + wz * wz, dist, dinv);
             Pinv = P < D_FLOOR ? 1.0 / D_FLOOR : Pinv;
             dinv = dist < D_FLOOR ? 1.0 / D_FLOOR : dinv;
-            const double phi = atan2(P, along);
+            const double phi = atan2_pos(P, along);
             const double ga = cutA > 0.0 ? fmin(1.0, pow_order(phi * rcp_nr(cutA), ordA)) : 1.0;
             const double gd = fmin(1.0, pow_order(cutD * dinv, ordD));
             const double k = -force * ga * gd * Pinv;
@@ -1349,7 +1367,7 @@ __global__ void __launch_bounds__(256) monitor_kernel(const T* pose, const T* fr
     const double c = 0.5 * (E[0] + E[4] + E[8] - 1.0);
     const double sn = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
     out[2 * t] = (T)sqrt(dx * dx + dy * dy + dz * dz);
-    out[2 * t + 1] = (T)(atan2(sn, c) * 57.295779513082320877);
+    out[2 * t + 1] = (T)(atan2_pos(sn, c) * 57.295779513082320877);
 }
 
 // ------------------------------------------------------------------------------------------------
