@@ -511,12 +511,22 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
     };
     constexpr int N_SLOT = 2 * PRE * Q16;                   // requests issued after the goal
-    constexpr int SLOTQ_PER_JOINT = (2 * PRE + NJ - 1) / NJ;  // slot quads requested after each joint
+    // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
+    // slot quads are requested into that wait, the remaining slot quads between the joints.
+#ifndef VFIK_EARLY_Q
+#define VFIK_EARLY_Q 6
+#endif
+    constexpr int EARLY_Q = VFIK_EARLY_Q;
+    constexpr int SLOTQ_PER_JOINT = (2 * PRE - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
+#pragma unroll
+    for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
-    VFIK_WAIT_VM(0);  // constants, tool and q have landed
+    VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, tool and q have landed (the goal and early slot requests may still be out)
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
     STAMP(2);
     {
@@ -567,10 +577,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) ang[i] = q[i] + klc->dh[i].off;
         sincos_fast_n<NJ>(ang, sn, cs);
     }
-    if (first) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
-    }
     double R[9], p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -607,7 +613,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
-            if (first && i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(i * SLOTQ_PER_JOINT + k);
+            if (first && EARLY_Q + i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(EARLY_Q + i * SLOTQ_PER_JOINT + k);
     }
     if (!PLAIN) {   // trailing z-screw of the last fixed transform
         const double tc = klc->tail_c, ts = klc->tail_s, te = klc->tail_e;
