@@ -1103,16 +1103,23 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) qn[i] += zp[FUSEP ? i : 0];
         }
-        // check_limits (nullspace:120-131) then gain (nullspace:183)
-        bool stop = false;
+        // check_limits (nullspace:120-131) then gain (nullspace:183).  The limits are fetched in one go and
+        // the test is bit arithmetic: written with `||` it became a chain of branches, each with its own
+        // scalar load and wait (~200 cycles a joint).
+        double lo[NJ], hi[NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) { lo[i] = kc->q_lo[i]; hi[i] = kc->q_hi[i]; }
+        const double look = kc->lookahead, ngain = kc->null_gain;
+        int bad = 0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
-            const double d = q[i] + kc->lookahead * qn[i];
-            stop = stop || d < kc->q_lo[i] || d > kc->q_hi[i];
+            const double d = q[i] + look * qn[i];
+            bad |= (int)(d < lo[i]) | (int)(d > hi[i]);
         }
+        const bool stop = bad != 0;
         if (stop) status |= VFIK_ST_LIMIT_STOP;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * kc->null_gain;
+        for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * ngain;
     }
 
     // ---------------- A15: command mixer (command_mixer.py:78-82) + limiter (bridge:188-195) ----
@@ -1134,16 +1141,20 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mac_unfused(0.0, qv[i], mw[0]), qn[i], mw[1]);
         if (a.q_ref) {  // joint P controller -> /bridge/jointcmd = channel 2 (joint_p_controller:78,89-99,124-128)
             const T* rf = static_cast<const T*>(a.q_ref) + (long)arm * NJ;
-            bool reached = true;
+            double rlo[NJ], rhi[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { rlo[i] = kc->q_lo[i]; rhi[i] = kc->q_hi[i]; }
+            const double delta = kc->jp_delta, kp = kc->jp_kp;
+            int far = 0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 const double rv = (double)rf[i];  // check_limits, joint_p_controller:89-99
-                const double ref = rv < kc->q_lo[i] ? kc->q_lo[i] : (rv > kc->q_hi[i] ? kc->q_hi[i] : rv);
+                const double ref = rv < rlo[i] ? rlo[i] : (rv > rhi[i] ? rhi[i] : rv);
                 const double err = ref - q[i];
-                reached = reached && err < kc->jp_delta;  // signed, as joint_p_controller:135 compares it
-                qo[i] = mac_unfused(qo[i], err * kc->jp_kp, mw[2]);
+                far |= (int)!(err < delta);  // signed, as joint_p_controller:135 compares it
+                qo[i] = mac_unfused(qo[i], err * kp, mw[2]);
             }
-            if (reached) status |= VFIK_ST_JOINT_AT_GOAL;
+            if (!far) status |= VFIK_ST_JOINT_AT_GOAL;
         }
         if (a.ext) {
             const T* e = static_cast<const T*>(a.ext);
@@ -1173,9 +1184,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             status |= VFIK_ST_LIMITED;
         }
     }
-    bool nan = false;
+    int nan = 0;
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) nan = nan || (qo[i] != qo[i]);
+    for (int i = 0; i < NJ; ++i) nan |= (int)(qo[i] != qo[i]);
     if (nan) status |= VFIK_ST_NAN;
 
     if (!ROLL || cyc == ncyc - 1) {  // the outputs are those of the last evaluated cycle
