@@ -717,7 +717,14 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
         if constexpr (FUSEP) {
             const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) zp[i] = jlt ? -kc->jl_k[i] * (q[i] - kc->q_mid[i]) : 0.0;  // -jl_gain (q - mid) / half^2
+            for (int i = 0; i < NJ; ++i) zp[i] = 0.0;
+            if (jlt) {  // -jl_gain (q - mid) / half^2; constants fetched together under the one uniform branch
+                double jk[NJ], qm[NJ];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) { jk[i] = kc->jl_k[i]; qm[i] = kc->q_mid[i]; }
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) zp[i] = -jk[i] * (q[i] - qm[i]);
+            }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 wn[r] = 0.0;
@@ -1251,9 +1258,13 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     }
     if (ROLL || a.q_out) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            q[i] = __builtin_fma(a.dt, qo[i], q[i]);
-            if (a.clamp) q[i] = fmin(fmax(q[i], kc->q_lo[i]), kc->q_hi[i]);
+        for (int i = 0; i < NJ; ++i) q[i] = __builtin_fma(a.dt, qo[i], q[i]);
+        if (a.clamp) {  // one uniform branch, the limits fetched together (not a load and a wait per joint)
+            double lo[NJ], hi[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { lo[i] = kc->q_lo[i]; hi[i] = kc->q_hi[i]; }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) q[i] = fmin(fmax(q[i], lo[i]), hi[i]);
         }
     }
     }  // cycles of this launch
