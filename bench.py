@@ -33,6 +33,8 @@ WORKLOADS = {
     "C2": ("lwr", 4096, 4, "float64", 0, 512),
     "C3": ("lwr", 65536, 8, "float32", 0, 384),
     "C5": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 696),
+    # C3 with the nullspace module and the mixer on, as `vfclik` starts them by default (vfclik:72-79); not a BASELINE config
+    "C3N": ("lwr", 65536, 8, "float32", 1 | 4, 384),
 }
 
 

@@ -15,7 +15,7 @@ from vfclik_amd import _abi, engine, robots, synth  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr_dual14", 65536, 16, np.float32, 7),
-                             "C2": ("lwr", 4096, 4, np.float64, 0)}[wl]
+                             "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5)}[wl]
 chain = robots.by_name(robot)
 w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io)
 eng = engine.Engine(chain, B, io_dtype=io, max_slots=nobs, params=_abi.default_params(flags=flags))

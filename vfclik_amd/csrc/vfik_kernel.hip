@@ -545,8 +545,9 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
     double lv_r[NJ];
-    if constexpr (NULLSP && ROLL && NJ <= 7) {  // (a single-cycle launch reads the state where it is used: fewer live
-        // registers; chains of 8+ joints have nullity >= 2 and never use the sign memory)
+    if constexpr (NULLSP && NJ <= 7) {  // requested here, a kinematics phase ahead of its use: read where it is used,
+        // the round trip stood in the wave's way (~1 500 cycles).  Chains of 8+ joints have nullity >= 2 and
+        // never use the sign memory.
         sig_r = a.sig[arm];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
@@ -1055,11 +1056,6 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                     if (!found && fabs(u[i]) > 1e-9) { found = true; sg = u[i] > 0.0 ? -1.0 : 1.0; }
                 }
                 // sign continuity against the previous cycle (nullspace:101-105)
-                if constexpr (!ROLL) {
-                    sig_r = a.sig[arm];
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
-                }
                 int sig = sig_r;
                 double dm = 0.0, dp = 0.0;
     #pragma unroll
