@@ -15,9 +15,12 @@ from vfclik_amd import _abi, engine, robots, synth  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr_dual14", 65536, 16, np.float32, 7),
-                             "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5)}[wl]
+                             "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5),
+                             "C3G": ("lwr", 65536, 8, np.float32, 0)}[wl]
 chain = robots.by_name(robot)
 w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io)
+if wl == "C3G":  # one arm with another decay order: the whole batch takes the general per-slot path
+    w["fields"]["p"][B // 2, 1, 5] = 2.0
 eng = engine.Engine(chain, B, io_dtype=io, max_slots=nobs, params=_abi.default_params(flags=flags))
 eng.set_fields(w["fields"], w["nfields"])
 dq = eng.dev_alloc(B * chain.n * np.dtype(io).itemsize)

@@ -297,14 +297,15 @@ __device__ __forceinline__ double slot_elem(const T* sq, long Q, int m, int e) {
 
 // One field slot of any type, read from memory (the general path: mixed primitive types in a wave,
 // fractional decay orders, more slots than the prefetch window).
-template <typename T>
-__device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const double* pt, double rot_slow, double cos_slow,
+// `rd(m, e)` = element e of slot m: SlotGlobal reads the quad planes in memory, SlotLds the rows staged in LDS.
+template <typename RD>
+__device__ void eval_slot(const RD& rd, int m, const double* Rt, const double* pt, double rot_slow, double cos_slow,
                           double* tot, double* sc) {
-    const int type = (int)slot_elem(sq, Q, m, 7);
+    const int type = (int)rd(m, 7);
     if (type <= 0) return;
-    const double p0 = slot_elem(sq, Q, m, 0), p1 = slot_elem(sq, Q, m, 1), p2 = slot_elem(sq, Q, m, 2),
-                 p3 = slot_elem(sq, Q, m, 3), p4 = slot_elem(sq, Q, m, 4), p5 = slot_elem(sq, Q, m, 5),
-                 force = slot_elem(sq, Q, m, 6);
+    const double p0 = rd(m, 0), p1 = rd(m, 1), p2 = rd(m, 2),
+                 p3 = rd(m, 3), p4 = rd(m, 4), p5 = rd(m, 5),
+                 force = rd(m, 6);
     if (type == VFIK_FIELD_REPELLER) {  // x y z radius safeDist order
         const double dx = p0 - pt[0], dy = p1 - pt[1], dz = p2 - pt[2];
         double D, Dinv;
@@ -314,7 +315,7 @@ __device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const do
         const double k = force * mag * Dinv;
         tot[0] += dx * k; tot[1] += dy * k; tot[2] += dz * k;
     } else if (type == VFIK_FIELD_HEMISPHERE) {  // x y z nx ny nz | safeDist order
-        const double safe = slot_elem(sq, Q, m + 1, 0), order = slot_elem(sq, Q, m + 1, 1);
+        const double safe = rd(m + 1, 0), order = rd(m + 1, 1);
         double nn, ninv;
         sqrt_rsqrt(p3 * p3 + p4 * p4 + p5 * p5, nn, ninv);
         if (nn > EPS_LEN) {
@@ -324,8 +325,8 @@ __device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const do
             tot[0] += p3 * k; tot[1] += p4 * k; tot[2] += p5 * k;
         }
     } else if (type == VFIK_FIELD_FUNNEL) {  // x y z ax ay az | cutAngle angleOrder cutDist distOrder
-        const double cutA = slot_elem(sq, Q, m + 1, 0), ordA = slot_elem(sq, Q, m + 1, 1),
-                     cutD = slot_elem(sq, Q, m + 1, 2), ordD = slot_elem(sq, Q, m + 1, 3);
+        const double cutA = rd(m + 1, 0), ordA = rd(m + 1, 1),
+                     cutD = rd(m + 1, 2), ordD = rd(m + 1, 3);
         double an, ainv;
         sqrt_rsqrt(p3 * p3 + p4 * p4 + p5 * p5, an, ainv);
         if (an > EPS_LEN) {
@@ -347,10 +348,10 @@ __device__ void eval_slot(const T* sq, long Q, int m, const double* Rt, const do
     } else if (type == VFIK_FIELD_ATTRACTOR) {  // a second attractor: frame16 + slow over 3 slots
         double GR[9], Gp[3];
         GR[0] = p0; GR[1] = p1; GR[2] = p2; Gp[0] = p3; GR[3] = p4; GR[4] = p5;
-        GR[5] = slot_elem(sq, Q, m + 1, 0); Gp[1] = slot_elem(sq, Q, m + 1, 1);
-        GR[6] = slot_elem(sq, Q, m + 1, 2); GR[7] = slot_elem(sq, Q, m + 1, 3); GR[8] = slot_elem(sq, Q, m + 1, 4);
-        Gp[2] = slot_elem(sq, Q, m + 1, 5);
-        attractor(Rt, pt, GR, Gp, slot_elem(sq, Q, m + 2, 4), force, rot_slow, cos_slow, true, tot, sc);
+        GR[5] = rd(m + 1, 0); Gp[1] = rd(m + 1, 1);
+        GR[6] = rd(m + 1, 2); GR[7] = rd(m + 1, 3); GR[8] = rd(m + 1, 4);
+        Gp[2] = rd(m + 1, 5);
+        attractor(Rt, pt, GR, Gp, rd(m + 2, 4), force, rot_slow, cos_slow, true, tot, sc);
     }
 }
 
@@ -414,6 +415,21 @@ __device__ __forceinline__ void read_quad(const char* region, int row, int lane,
         out[0] = lo.x; out[1] = lo.y; out[2] = hi.x; out[3] = hi.y;
     }
 }
+
+// slot readers for eval_slot
+template <typename T> struct SlotGlobal {
+    const T* sq; long Q;  // plane 0, component 0 of this lane's arm; plane pitch in elements
+    __device__ __forceinline__ double operator()(int m, int e) const { return slot_elem(sq, Q, m, e); }
+};
+template <typename T> struct SlotLds {
+    const char* region; int lane;  // the wave's staging region: slot m sits in quads 2m, 2m + 1 of the slot rows (m < PRE)
+    __device__ __forceinline__ double operator()(int m, int e) const {
+        const int quad = 2 * m + (e >> 2), c = e & 3;
+        if (Stage<T>::Q16 == 1)
+            return (double)*reinterpret_cast<const float*>(region + (Stage<T>::ROW_SLOT + quad) * 1024 + lane * 16 + c * 4);
+        return *reinterpret_cast<const double*>(region + (Stage<T>::ROW_SLOT + 2 * quad + (c >> 1)) * 1024 + lane * 16 + (c & 1) * 8);
+    }
+};
 
 #define VFIK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -869,8 +885,78 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
                 chunk(c0);
             }
         } else {
-            VFIK_WAIT_VM(0);  // (the staged slots are not used on the general path)
-            for (int m = 0; m < a.slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, kc->rot_slow, kc->cos_slow, tot, sc);
+            // General path (mixed primitive types, fractional or differing orders): slot by slot.  The first
+            // PRE slots are read from the rows staged in LDS during the kinematics -- read from memory, every
+            // slot cost a round trip of its own (C3 with one odd arm: 10.9 us per launch) -- the rest, and
+            // entries that would straddle the staged window, from the quad planes.
+            VFIK_WAIT_VM(0);
+            const SlotLds<T> rl{region, lanec};
+            const SlotGlobal<T> rg{sq, Qp};
+            const double rs = kc->rot_slow, csl = kc->cos_slow;
+            // Stage A: the decay repellers with an integer order among the staged slots, all together as in
+            // the straight-line path (slot by slot the dependent chains of sqrt and power cost ~1 600 cycles a
+            // slot); the order may differ from lane to lane and slot to slot: square-and-multiply over the
+            // bits of the largest order in the wave, each lane selecting by its own bits.
+            unsigned done = 0;  // bit m: slot m was handled here (per lane)
+            {
+                double dx[PRE], dy[PRE], dz[PRE], rsum[PRE], fk[PRE], di[PRE], rb[PRE], rp[PRE];
+                int nn[PRE];
+                int nmax = 0;
+#pragma unroll
+                for (int m = 0; m < PRE; ++m) {
+                    double s0[4], s1[4];
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
+                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
+                    const int n = (int)s1[1];
+                    const bool ok = m < npre && (int)s1[3] == VFIK_FIELD_REPELLER && (double)n == s1[1] && n >= 0 && n < 128;
+                    dx[m] = s0[0] - pt[0]; dy[m] = s0[1] - pt[1]; dz[m] = s0[2] - pt[2];
+                    rsum[m] = s0[3] + s1[0];
+                    fk[m] = ok ? s1[2] : 0.0;
+                    nn[m] = ok ? n : 0;
+                    nmax |= nn[m];
+                    done |= ok ? (1u << m) : 0u;
+                }
+#pragma unroll
+                for (int m = 0; m < PRE; ++m) {
+                    double D;
+                    sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
+                    di[m] = fmin(di[m], 1.0 / D_FLOOR);
+                    rb[m] = rsum[m] * di[m];
+                    rp[m] = 1.0;
+                }
+                int top = 0;  // number of order bits in use anywhere in the wave (uniform)
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    if (__any((nmax >> k) != 0)) top = k + 1;
+                for (int k = 0; k < top; ++k) {
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) rp[m] = (nn[m] >> k) & 1 ? rp[m] * rb[m] : rp[m];
+                    if (k + 1 < top) {
+#pragma unroll
+                        for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < PRE; ++m) {
+                    const double k = (done >> m) & 1 ? fk[m] * fmin(rp[m], MAG_CAP) * di[m] : 0.0;  // a select: the unused slots may hold anything
+                    tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+                }
+            }
+            // Stage B: every other entry, one at a time: from the staged rows when the whole entry lies in
+            // them, else from the quad planes in memory.
+            for (int m = 0; m < a.slots_used; ++m) {
+                if (m < PRE && __all((done >> m) & 1)) continue;
+                bool staged = false;
+                if (m < npre) {  // an entry spans 1 (repeller), 2 (hemisphere, funnel) or 3 (attractor) slots
+                    const int t = (int)rl(m, 7);
+                    const int span = t == VFIK_FIELD_ATTRACTOR ? 3 : (t == VFIK_FIELD_HEMISPHERE || t == VFIK_FIELD_FUNNEL) ? 2 : 1;
+                    staged = m + span <= npre;
+                }
+                const bool skip = m < PRE && ((done >> m) & 1);
+                if (skip) continue;
+                if (staged) eval_slot(rl, m, Rt, pt, rs, csl, tot, sc);
+                else eval_slot(rg, m, Rt, pt, rs, csl, tot, sc);
+            }
         }
     }
     PIN_ARR(tot, 6);
@@ -1426,7 +1512,8 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
     }
     attractor(Rt, pt, GR, Gp, gq[13], gq[14], rot_slow, cos_slow, gq[12] != 0.0, tot, sc, nullptr);
     const T* sq = slots + (long)arm * 4;
-    for (int m = 0; m < slots_used; ++m) eval_slot<T>(sq, Qp, m, Rt, pt, rot_slow, cos_slow, tot, sc);
+    const SlotGlobal<T> rg{sq, Qp};
+    for (int m = 0; m < slots_used; ++m) eval_slot(rg, m, Rt, pt, rot_slow, cos_slow, tot, sc);
     double nt, nti, nr, nri;
     sqrt_rsqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2], nt, nti);
     sqrt_rsqrt(tot[3] * tot[3] + tot[4] * tot[4] + tot[5] * tot[5], nr, nri);
