@@ -42,3 +42,22 @@ F["p"][:, 7, 0:3] = F["p"][:, 0, [3, 7, 11]] - 0.05 * F["p"][:, 0, [2, 6, 10]]
 F["p"][:, 7, 3:6] = [0.05, 0.001, 5.0]
 w["nfields"][:] = 8
 run("goalAndNormal + 5 obstacles", w, 10)
+chain = robots.lwr_dual14()
+w = synth.make_workload(chain, B, 16, seed=1, io_dtype=np.float32)
+
+
+def run14(name, w):
+    eng = engine.Engine(chain, B, io_dtype=np.float32, max_slots=16, params=_abi.default_params(flags=7))
+    eng.set_fields(w["fields"], w["nfields"])
+    dq = eng.dev_alloc(B * 14 * 4)
+    do = eng.dev_alloc(B * 14 * 4)
+    eng.h2d(dq, w["q"].astype(np.float32))
+    io = eng.make_io(dq, qdot_out=do)
+    ms = eng.time_steps(io, 20, 200)
+    print("%-34s %.2f us per step" % (name, ms * 1e3 / 200))
+    eng.close()
+
+
+run14("C5, straight-line path", w)
+w["fields"]["p"][0, 12, 5] = 2.0
+run14("C5, one arm with another order", w)

@@ -889,73 +889,80 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
             // PRE slots are read from the rows staged in LDS during the kinematics -- read from memory, every
             // slot cost a round trip of its own (C3 with one odd arm: 10.9 us per launch) -- the rest, and
             // entries that would straddle the staged window, from the quad planes.
-            VFIK_WAIT_VM(0);
             const SlotLds<T> rl{region, lanec};
-            const SlotGlobal<T> rg{sq, Qp};
             const double rs = kc->rot_slow, csl = kc->cos_slow;
-            // Stage A: the decay repellers with an integer order among the staged slots, all together as in
-            // the straight-line path (slot by slot the dependent chains of sqrt and power cost ~1 600 cycles a
-            // slot); the order may differ from lane to lane and slot to slot: square-and-multiply over the
-            // bits of the largest order in the wave, each lane selecting by its own bits.
-            unsigned done = 0;  // bit m: slot m was handled here (per lane)
-            {
-                double dx[PRE], dy[PRE], dz[PRE], rsum[PRE], fk[PRE], di[PRE], rb[PRE], rp[PRE];
-                int nn[PRE];
-                int nmax = 0;
+            for (int c0 = 0; c0 < a.slots_used; c0 += PRE) {  // chunks of PRE slots through the staged rows
+                if (c0 > 0) {  // (no overlap with the previous chunk's arithmetic here: its entries read the rows lazily)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int m = 0; m < PRE; ++m) {
-                    double s0[4], s1[4];
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
-                    const int n = (int)s1[1];
-                    const bool ok = m < npre && (int)s1[3] == VFIK_FIELD_REPELLER && (double)n == s1[1] && n >= 0 && n < 128;
-                    dx[m] = s0[0] - pt[0]; dy[m] = s0[1] - pt[1]; dz[m] = s0[2] - pt[2];
-                    rsum[m] = s0[3] + s1[0];
-                    fk[m] = ok ? s1[2] : 0.0;
-                    nn[m] = ok ? n : 0;
-                    nmax |= nn[m];
-                    done |= ok ? (1u << m) : 0u;
-                }
-#pragma unroll
-                for (int m = 0; m < PRE; ++m) {
-                    double D;
-                    sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
-                    di[m] = fmin(di[m], 1.0 / D_FLOOR);
-                    rb[m] = rsum[m] * di[m];
-                    rp[m] = 1.0;
-                }
-                int top = 0;  // number of order bits in use anywhere in the wave (uniform)
-#pragma unroll
-                for (int k = 0; k < 7; ++k)
-                    if (__any((nmax >> k) != 0)) top = k + 1;
-                for (int k = 0; k < top; ++k) {
-#pragma unroll
-                    for (int m = 0; m < PRE; ++m) rp[m] = (nn[m] >> k) & 1 ? rp[m] * rb[m] : rp[m];
-                    if (k + 1 < top) {
-#pragma unroll
-                        for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                    for (int idx = 0; idx < 2 * PRE; ++idx) {
+                        const int m = c0 + (idx >> 1);
+                        const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+                        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
                     }
                 }
+                VFIK_WAIT_VM(0);
+                const int ncur = a.slots_used - c0 < PRE ? a.slots_used - c0 : PRE;  // slots of this chunk in use
+                const SlotGlobal<T> rg{sq + (long)c0 * 2 * Qp, Qp};  // the same slots in memory: local index m = slot c0 + m
+                // Stage A: the decay repellers with an integer order among the staged slots, all together as in
+                // the straight-line path (slot by slot the dependent chains of sqrt and power cost ~1 600 cycles a
+                // slot); the order may differ from lane to lane and slot to slot: square-and-multiply over the
+                // bits of the largest order in the wave, each lane selecting by its own bits.
+                unsigned done = 0;  // bit m: slot m of the chunk was handled here (per lane)
+                {
+                    double dx[PRE], dy[PRE], dz[PRE], rsum[PRE], fk[PRE], di[PRE], rb[PRE], rp[PRE];
+                    int nn[PRE];
+                    int nmax = 0;
 #pragma unroll
-                for (int m = 0; m < PRE; ++m) {
-                    const double k = (done >> m) & 1 ? fk[m] * fmin(rp[m], MAG_CAP) * di[m] : 0.0;  // a select: the unused slots may hold anything
-                    tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+                    for (int m = 0; m < PRE; ++m) {
+                        double s0[4], s1[4];
+                        read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
+                        read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
+                        const int n = (int)s1[1];
+                        const bool ok = m < ncur && (int)s1[3] == VFIK_FIELD_REPELLER && (double)n == s1[1] && n >= 0 && n < 128;
+                        dx[m] = s0[0] - pt[0]; dy[m] = s0[1] - pt[1]; dz[m] = s0[2] - pt[2];
+                        rsum[m] = s0[3] + s1[0];
+                        fk[m] = ok ? s1[2] : 0.0;
+                        nn[m] = ok ? n : 0;
+                        nmax |= nn[m];
+                        done |= ok ? (1u << m) : 0u;
+                    }
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) {
+                        double D;
+                        sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
+                        di[m] = fmin(di[m], 1.0 / D_FLOOR);
+                        rb[m] = rsum[m] * di[m];
+                        rp[m] = 1.0;
+                    }
+                    int top = 0;  // number of order bits in use anywhere in the wave (uniform)
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                        if (__any((nmax >> k) != 0)) top = k + 1;
+                    for (int k = 0; k < top; ++k) {
+#pragma unroll
+                        for (int m = 0; m < PRE; ++m) rp[m] = (nn[m] >> k) & 1 ? rp[m] * rb[m] : rp[m];
+                        if (k + 1 < top) {
+#pragma unroll
+                            for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) {
+                        const double k = (done >> m) & 1 ? fk[m] * fmin(rp[m], MAG_CAP) * di[m] : 0.0;  // a select: the unused slots may hold anything
+                        tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
+                    }
                 }
-            }
-            // Stage B: every other entry, one at a time: from the staged rows when the whole entry lies in
-            // them, else from the quad planes in memory.
-            for (int m = 0; m < a.slots_used; ++m) {
-                if (m < PRE && __all((done >> m) & 1)) continue;
-                bool staged = false;
-                if (m < npre) {  // an entry spans 1 (repeller), 2 (hemisphere, funnel) or 3 (attractor) slots
-                    const int t = (int)rl(m, 7);
+                // Stage B: every other entry, one at a time: from the staged rows when the whole entry lies in
+                // them, else (it runs into the next chunk) from the quad planes in memory.
+                for (int m = 0; m < ncur; ++m) {
+                    if (__all((done >> m) & 1)) continue;
+                    const int t = (int)rl(m, 7);  // an entry spans 1 (repeller), 2 (hemisphere, funnel) or 3 (attractor) slots
                     const int span = t == VFIK_FIELD_ATTRACTOR ? 3 : (t == VFIK_FIELD_HEMISPHERE || t == VFIK_FIELD_FUNNEL) ? 2 : 1;
-                    staged = m + span <= npre;
+                    if ((done >> m) & 1) continue;
+                    if (m + span <= ncur) eval_slot(rl, m, Rt, pt, rs, csl, tot, sc);
+                    else eval_slot(rg, m, Rt, pt, rs, csl, tot, sc);
                 }
-                const bool skip = m < PRE && ((done >> m) & 1);
-                if (skip) continue;
-                if (staged) eval_slot(rl, m, Rt, pt, rs, csl, tot, sc);
-                else eval_slot(rg, m, Rt, pt, rs, csl, tot, sc);
             }
         }
     }
