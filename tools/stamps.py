@@ -16,9 +16,20 @@ from vfclik_amd import _abi, engine, robots, synth  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr_dual14", 65536, 16, np.float32, 7),
                              "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5),
-                             "C3G": ("lwr", 65536, 8, np.float32, 0)}[wl]
+                             "C3G": ("lwr", 65536, 8, np.float32, 0), "GAN": ("lwr", 65536, 5, np.float32, 0)}[wl]
 chain = robots.by_name(robot)
-w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io)
+w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io, max_fields=8 if wl == "GAN" else None)
+if wl == "GAN":  # goalAndNormal scene (object_feeder:248-303): attractor + funnel + near-goal repeller + 5 obstacles
+    F = w["fields"]
+    F["id"][:, 6], F["type"][:, 6], F["force"][:, 6] = 2, 5, 30.0
+    F["p"][:, 6, 0:3] = F["p"][:, 0, [3, 7, 11]]
+    F["p"][:, 6, 3:6] = F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 6, 6:10] = [0.15, 10.0, 0.15, 2.0]
+    F["id"][:, 7], F["type"][:, 7], F["force"][:, 7] = 3, 2, -10.0
+    F["p"][:, 7, 0:3] = F["p"][:, 0, [3, 7, 11]] - 0.05 * F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 7, 3:6] = [0.05, 0.001, 5.0]
+    w["nfields"][:] = 8
+    nobs = 10
 if wl == "C3G":  # one arm with another decay order: the whole batch takes the general per-slot path
     w["fields"]["p"][B // 2, 1, 5] = 2.0
 eng = engine.Engine(chain, B, io_dtype=io, max_slots=nobs, params=_abi.default_params(flags=flags))
