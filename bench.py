@@ -35,6 +35,7 @@ WORKLOADS = {
     "C5": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 696),
     # C3 with the nullspace module and the mixer on, as `vfclik` starts them by default (vfclik:72-79); not a BASELINE config
     "C3N": ("lwr", 65536, 8, "float32", 1 | 4, 384),
+    "C3D": ("lwr", 65536, 8, "float64", 0, 768),  # C3 with float64 I/O (not a BASELINE config)
 }
 
 

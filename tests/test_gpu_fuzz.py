@@ -1,6 +1,8 @@
 """Randomised differential test: 36 seeded configurations (chain, batch size, dtype, feature flags, field
 mix, tools, weights, speed scales, external channels) through the C-ABI against the CPU oracle.  Batch
 sizes straddle the wave size (1, 63, 64, 65, ...), field lists are ragged and include the general path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -50,7 +52,7 @@ def _random_fields(abi, chain, B, rng, dt, general):
     return F, n
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VFIK_FUZZ_SEEDS", "36"))))  # more seeds: VFIK_FUZZ_SEEDS=400
 def test_random_configuration(env, seed):
     abi = env["abi"]
     rng = np.random.default_rng(1000 + seed)
