@@ -16,7 +16,8 @@ from vfclik_amd import _abi, engine, robots, synth  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr_dual14", 65536, 16, np.float32, 7),
                              "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5),
-                             "C3G": ("lwr", 65536, 8, np.float32, 0), "GAN": ("lwr", 65536, 5, np.float32, 0)}[wl]
+                             "C3G": ("lwr", 65536, 8, np.float32, 0), "GAN": ("lwr", 65536, 5, np.float32, 0),
+                             "C3D": ("lwr", 65536, 8, np.float64, 0)}[wl]
 chain = robots.by_name(robot)
 w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io, max_fields=8 if wl == "GAN" else None)
 if wl == "GAN":  # goalAndNormal scene (object_feeder:248-303): attractor + funnel + near-goal repeller + 5 obstacles

@@ -355,7 +355,6 @@ __device__ void eval_slot(const RD& rd, int m, const double* Rt, const double* p
     }
 }
 
-constexpr int PRE = 8;  // slots whose loads are issued before the kinematics (prefetch window)
 
 // ------------------------------------------------------------------------------------------------
 // Staging through LDS (direct global -> LDS loads, no VGPR destination).  Every lane's inputs of
@@ -367,6 +366,10 @@ constexpr int PRE = 8;  // slots whose loads are issued before the kinematics (p
 //     then the kinematics block of KConst (1-2 KiB)
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Stage {
+    // Slots staged at a time (prefetch window / chunk size).  float64 I/O stages 4: with 8 the region is 56 KB
+    // and only three of a CU's four SIMDs get a wave (160 KB LDS) -- the launch then runs in two rounds
+    // (measured 15.3 us instead of ~8 for the C3 batch).
+    static constexpr int PRE = sizeof(T) == 8 ? 4 : 8;
     static constexpr int Q16 = (int)sizeof(T) / 4;           // 16-B pieces per quad
     static constexpr int QROWS = (3 + 4 + 2 * PRE + 2) * Q16;  // 1 KiB rows
     static constexpr int ROW_TOOL = 0, ROW_GOAL = 3 * Q16, ROW_SLOT = 7 * Q16, ROW_MIXW = (7 + 2 * PRE) * Q16;
@@ -484,6 +487,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * Stage<T>::bytes(NJ);
     const long Bp = a.Bpad;
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
+    constexpr int PRE = Stage<T>::PRE;
     const long planeB = Bp * QB;  // bytes of one quad plane
     {   // kinematics constants (oldest request: covered by the first wait).  All 64 lanes copy
         // 16 bytes each, so this comes before the lanes past the end of the batch retire.
