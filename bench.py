@@ -248,10 +248,10 @@ def main():
             "max_abs_err_rad_s": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         # <io type, joints, nullspace module, PLAIN>: the bench workloads (revolute chain, identity
-                         # tool, unit weights) take the PLAIN variant
-                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true>" % ("float" if io_name == "float32" else "double", chain.n,
-                                                                        "true" if flags & 1 else "false"),
+                         # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path>: the bench workloads
+                         # (revolute chain, identity tool, unit weights, integer-order repellers) take PLAIN and the last
+                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true>" % ("float" if io_name == "float32" else "double", chain.n,
+                                                                                   "true" if flags & 1 else "false"),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle, "us_per_launch_hip_events": us_per_launch},
         }
         if rollout is not None:

@@ -466,7 +466,7 @@ template <typename T> struct SlotLds {
 // ROLL = closed-loop rollout: a.n_cycles control cycles in one launch, the joint angles
 // integrated in registers (q += dt * qdot_out, the role of the external joint_sim, vfclik:99-103), the
 // field set read from LDS every cycle; one launch boundary and one set of loads per n_cycles cycles.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF>
 __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
     {
         const T* sq = static_cast<const T*>(a.slots) + (long)arm * 4;
         const long Qp = Bp * 4;
-        if (a.fast_order >= 0) {
+        if constexpr (FASTF) {  // (the host launches this variant when a.fast_order >= 0)
             // Fast path, decided by the host when the field sets were packed (vfik_set_fields): every
             // used slot of every arm is a decay repeller with the same integer decay order -- what
             // object_feeder produces for point obstacles (object_feeder:317-334).  Empty slots carry
@@ -1540,13 +1540,18 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
 
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
+    // one, the general path's code cost the straight-line launches 2.7 % (register allocation and layout).
+    const bool fastf = a.fast_order >= 0;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true>), grid, blk, lds, stream, a);
+            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true>), grid, blk, lds, stream, a);
+            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false>), grid, blk, lds, stream, a);
             return;
         }
     }
-    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false>), grid, blk, lds, stream, a);
+    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true>), grid, blk, lds, stream, a);
+    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false>), grid, blk, lds, stream, a);
 }
 
 template <typename T, int NJ>
