@@ -248,9 +248,9 @@ def main():
             "max_abs_err_rad_s": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path>: the bench workloads
-                         # (revolute chain, identity tool, unit weights, integer-order repellers) take PLAIN and the last
-                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true>" % ("float" if io_name == "float32" else "double", chain.n,
+                         # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN>: the bench
+                         # workloads (revolute chain, identity tool, unit weights, integer-order repellers, qdot_out only)
+                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true,true>" % ("float" if io_name == "float32" else "double", chain.n,
                                                                                    "true" if flags & 1 else "false"),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle, "us_per_launch_hip_events": us_per_launch},
         }

@@ -526,3 +526,25 @@ def test_properties_full_size(env):
     c = eng.step_host(w["q"], want=("qdot_vf",))
     assert np.all(c["qdot_vf"] == 0.0)
     eng.close()
+
+
+@pytest.mark.parametrize("robot,dt,flags", [("lwr", np.float32, 0), ("lwr", np.float64, 0), ("powercube6", np.float64, 0),
+                                            ("lwr", np.float64, 1 | 4), ("lwr", np.float32, 1 | 4 | 8), ("lwr_dual14", np.float32, 1 | 2 | 4),
+                                            ("lwr_dual14", np.float64, 1 | 2 | 4), ("lwr_dual14", np.float64, 0)])
+def test_lean_kernel_variant_only_qdot_out(env, robot, dt, flags):
+    """q -> qdot_out and nothing else selects the LEAN kernel variant (no optional input or output compiled in):
+    the same numbers as the full variant, which the same engine runs as soon as a second output is asked for."""
+    chain = env.robots.by_name(robot)
+    B = 1000
+    w = env.synth.make_workload(chain, B, 6, seed=27, io_dtype=dt)
+    params = env.abi.default_params(flags=flags, max_vel=0.7)
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    lean = eng.step_host(w["q"], want=("qdot_out",))
+    eng.reset_state()
+    full = eng.step_host(w["q"], want=("qdot_out", "status", "pose"))
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"])
+    tol = TOL64 if dt == np.float64 else 2e-6
+    assert np.abs(lean["qdot_out"] - ref["qdot_out"]).max() < tol
+    assert np.abs(lean["qdot_out"].astype(np.float64) - full["qdot_out"]).max() < (1e-12 if dt == np.float64 else 5e-7)
+    eng.close()

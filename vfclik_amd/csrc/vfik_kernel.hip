@@ -466,8 +466,18 @@ template <typename T> struct SlotLds {
 // ROLL = closed-loop rollout: a.n_cycles control cycles in one launch, the joint angles
 // integrated in registers (q += dt * qdot_out, the role of the external joint_sim, vfclik:99-103), the
 // field set read from LDS every cycle; one launch boundary and one set of loads per n_cycles cycles.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF>
-__global__ void __launch_bounds__(256) cycle_kernel(const KArgs a) {
+// LEAN = nothing but q -> qdot_out: no optional input or output (and, without the nullspace module, no feature flag):
+// the BASELINE C3 and C5 launches.  The arguments that select those options are compile-time nulls, so their code is
+// not in the kernel at all -- present but never executed, it cost the C3 launch 4.5 % (6.47 -> 6.18 us, same box).
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, bool LEAN>
+__global__ void __launch_bounds__(256) cycle_kernel(const KArgs a_in) {
+    KArgs a = a_in;
+    if constexpr (LEAN) {
+        if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
+        a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
+        a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
+        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status = nullptr; a.q_out = nullptr; a.status_or = 0;
+    }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
     asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots),
@@ -1545,13 +1555,21 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     const bool fastf = a.fast_order >= 0;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
-            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true>), grid, blk, lds, stream, a);
-            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false>), grid, blk, lds, stream, a);
+            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, false>), grid, blk, lds, stream, a);
+            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, false>), grid, blk, lds, stream, a);
             return;
         }
     }
-    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true>), grid, blk, lds, stream, a);
-    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false>), grid, blk, lds, stream, a);
+    if constexpr (PL) {
+        const bool lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.q_ref && !a.q_cmded &&
+                          !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.status && !a.q_out;
+        if (lean) {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, true>), grid, blk, lds, stream, a);
+            return;
+        }
+    }
+    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, false>), grid, blk, lds, stream, a);
+    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, false>), grid, blk, lds, stream, a);
 }
 
 template <typename T, int NJ>
