@@ -469,8 +469,10 @@ template <typename T> struct SlotLds {
 // LEAN = nothing but q -> qdot_out: no optional input or output (and, without the nullspace module, no feature flag):
 // the BASELINE C3 and C5 launches.  The arguments that select those options are compile-time nulls, so their code is
 // not in the kernel at all -- present but never executed, it cost the C3 launch 4.5 % (6.47 -> 6.18 us, same box).
+// amdgpu_waves_per_eu(1, 1): one wave per SIMD is what the launch gets anyway (registers, LDS); telling the backend
+// lets its scheduler stop trading instruction order for a register count it cannot use (C3 -2.4 %, same-box A/B).
 template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, bool LEAN>
-__global__ void __launch_bounds__(256) cycle_kernel(const KArgs a_in) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) cycle_kernel(const KArgs a_in) {
     KArgs a = a_in;
     if constexpr (LEAN) {
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
