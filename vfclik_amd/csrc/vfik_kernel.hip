@@ -875,6 +875,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     rb[m] = rs[m] * di[m];
                     rp[m] = 1.0;
                 }
+                if (n0 == 5) {  // what object_feeder sends (object_feeder:302,333): no loop, no branches
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) { const double b2 = rb[m] * rb[m]; rp[m] = b2 * b2 * rb[m]; }
+                } else {
                 for (int e = n0; e;) {  // square-and-multiply, all slots in lock step
                     if (e & 1) {
 #pragma unroll
@@ -885,6 +889,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                         for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
                     }
+                }
                 }
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
