@@ -55,6 +55,25 @@ def test_rollout_matches_stepped_oracle(env, robot, nobs, flags):
     eng.close()
 
 
+@pytest.mark.parametrize("robot,dt_io,flags", [("lwr", np.float32, 0), ("lwr", np.float64, 0), ("lwr", np.float64, 1 | 4), ("powercube6", np.float32, 1 | 4 | 8),
+                                               ("lwr_dual14", np.float64, 1 | 2 | 4)])
+def test_lean_rollout_only_q_and_qdot_out(env, robot, dt_io, flags):
+    """A rollout that asks for nothing but q and qdot_out runs the LEAN variant (7 joints and fewer; longer chains are
+    stepped launches either way): same trajectory as the oracle stepped on the host."""
+    chain = env.robots.by_name(robot)
+    B, K, dt = 777, 30, 0.01
+    w = env.synth.make_workload(chain, B, 5, seed=37, io_dtype=dt_io)
+    params = env.abi.default_params(flags=flags, max_vel=0.7)
+    eng = env.engine.Engine(chain, B, io_dtype=dt_io, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    got = eng.rollout_host(w["q"], K, dt, clamp=True, want=("qdot_out",))
+    q_ref, ref, _ = _oracle_rollout(env, chain, params, w, K, dt, None, clamp=True)
+    tol_q, tol_v = (1e-8, 1e-7) if dt_io == np.float64 else (2e-6, 2e-5)
+    assert np.abs(got["q"] - q_ref).max() < tol_q, np.abs(got["q"] - q_ref).max()
+    assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < tol_v
+    eng.close()
+
+
 def test_rollout_equals_repeated_single_launches(env):
     chain = env.robots.lwr()
     B, K, dt = 4096, 25, 0.004

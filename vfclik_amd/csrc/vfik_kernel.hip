@@ -478,7 +478,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
         a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
         a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
-        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status = nullptr; a.q_out = nullptr; a.status_or = 0;
+        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status = nullptr; a.status_or = 0;
+        if constexpr (!ROLL) a.q_out = nullptr;  // (a rollout's q_out is its result)
     }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
@@ -1560,17 +1561,25 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
     // one, the general path's code cost the straight-line launches 2.7 % (register allocation and layout).
     const bool fastf = a.fast_order >= 0;
+    bool lean = false;
+    if constexpr (PL)
+        lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.q_ref && !a.q_cmded &&
+               !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.status;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
+            if constexpr (PL) {
+                if (lean) {
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, true>), grid, blk, lds, stream, a);
+                    return;
+                }
+            }
             if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, false>), grid, blk, lds, stream, a);
             else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, false>), grid, blk, lds, stream, a);
             return;
         }
     }
     if constexpr (PL) {
-        const bool lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.q_ref && !a.q_cmded &&
-                          !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.status && !a.q_out;
-        if (lean) {
+        if (lean && !a.q_out) {
             hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, true>), grid, blk, lds, stream, a);
             return;
         }
