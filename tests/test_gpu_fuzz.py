@@ -105,4 +105,8 @@ def test_random_configuration(env, seed):
             assert np.isfinite(got[k]).all(), (seed, k)
             err = np.abs(got[k].astype(np.float64) - ref[k]).max()
             assert err < tol, (seed, robot, B, k, err)
+    # the same launch asking for qdot_out alone (the LEAN kernel variant where the configuration allows it)
+    eng.reset_state()
+    alone = eng.step_host(q, null_control=ctrl, want=("qdot_out",))
+    assert np.abs(alone["qdot_out"].astype(np.float64) - ref["qdot_out"]).max() < tol, (seed, "qdot_out alone")
     eng.close()

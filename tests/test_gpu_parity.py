@@ -548,3 +548,22 @@ def test_lean_kernel_variant_only_qdot_out(env, robot, dt, flags):
     assert np.abs(lean["qdot_out"] - ref["qdot_out"]).max() < tol
     assert np.abs(lean["qdot_out"].astype(np.float64) - full["qdot_out"]).max() < (1e-12 if dt == np.float64 else 5e-7)
     eng.close()
+
+
+def test_lean_selection_honours_external_channels(env):
+    """Only qdot_out requested, but mixer channels 2..5 carry commands: the launch must not take the LEAN variant
+    (which has no external channels compiled in)."""
+    chain = env.robots.lwr()
+    B = 500
+    f = env.abi
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER, mix_w=[1, 1, 0.5, 0.25, 0, 1])
+    w = env.synth.make_workload(chain, B, 4, seed=33, io_dtype=np.float64)
+    ext = np.random.default_rng(33).normal(size=(4, B, 7))
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    for ch in range(4):
+        eng.set_ext_cmd(2 + ch, ext[ch])
+    got = eng.step_host(w["q"], want=("qdot_out",))
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], ext_cmd=ext)
+    assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < TOL64
+    eng.close()
