@@ -74,6 +74,33 @@ def test_lean_rollout_only_q_and_qdot_out(env, robot, dt_io, flags):
     eng.close()
 
 
+@pytest.mark.parametrize("robot", ["lwr", "lwr_dual14"])
+def test_rollout_on_the_general_field_path(env, robot):
+    """Mixed field sets (a funnel, a hemisphere, fractional and differing decay orders, 11 slots) send the batch down
+    the general field path: the in-kernel loop (7 joints) and the stepped launches (14) against the stepped oracle."""
+    chain = env.robots.by_name(robot)
+    B, K, dt = 600, 20, 0.01
+    w = env.synth.make_workload(chain, B, 7, seed=41, io_dtype=np.float64, max_fields=10)
+    F = w["fields"]
+    F["p"][::3, 2, 5] = 2.0          # another integer order on every third arm
+    F["p"][1::3, 3, 5] = 2.5         # a fractional order
+    F["id"][:, 8], F["type"][:, 8], F["force"][:, 8] = 2, 5, 30.0   # funnel
+    F["p"][:, 8, :10] = [0.3, 0.2, 0.5, 0.1, 0.2, -0.9, 0.15, 10.0, 0.15, 2.0]
+    F["id"][:, 9], F["type"][:, 9], F["force"][:, 9] = 40, 4, -50.0  # hemisphere
+    F["p"][:, 9, :8] = [0.2, -0.1, -0.5, 0.05, -0.02, 1.0, 0.05, 5.0]
+    w["nfields"][:] = 10
+    params = env.abi.default_params(flags=env.abi.F_MIXER | env.abi.F_LIMITER, max_vel=0.7)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=12, params=params)
+    eng.set_fields(F, w["nfields"])
+    assert eng.lib.vfik_slots_in_use(eng.h) == 11
+    got = eng.rollout_host(w["q"], K, dt, clamp=True, want=("qdot_out", "status"))
+    q_ref, ref, st_ref = _oracle_rollout(env, chain, params, w, K, dt, None, clamp=True)
+    assert np.abs(got["q"] - q_ref).max() < 1e-8, np.abs(got["q"] - q_ref).max()
+    assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < 1e-7
+    assert np.array_equal(got["status"], st_ref)
+    eng.close()
+
+
 def test_rollout_equals_repeated_single_launches(env):
     chain = env.robots.lwr()
     B, K, dt = 4096, 25, 0.004
