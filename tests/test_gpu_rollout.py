@@ -101,6 +101,29 @@ def test_rollout_on_the_general_field_path(env, robot):
     eng.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1 | 4])
+def test_rollout_with_tool_and_weights(env, flags):
+    """The general (non-PLAIN) kernel variants in the rollout loop: a tool offset and non-unit IK weights."""
+    chain = env.robots.lwr()
+    B, K, dt = 512, 25, 0.01
+    w = env.synth.make_workload(chain, B, 4, seed=43, io_dtype=np.float64)
+    params = env.abi.default_params(flags=flags, wy=[1, 1, 1, 0.3, 0.3, 0.1], wq=[1, 0.5, 1, 0.7, 1, 0.4, 1] + [1.0] * 9)
+    tool = np.eye(4)
+    tool[:3, 3] = [0.02, -0.01, 0.2]
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_tool(tool.reshape(16))
+    got = eng.rollout_host(w["q"], K, dt, want=("qdot_out", "pose"))
+    q = w["q"].copy()
+    states = env.oc.new_states(B, 7) if flags & 1 else None
+    for _ in range(K):
+        ref = env.oc.cycle_batch(chain, params, q, w["fields"], w["nfields"], tool=tool.reshape(16), states=states)
+        q = q + dt * ref["qdot_out"]
+    assert np.abs(got["q"] - q).max() < 1e-8
+    assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < 1e-7 and np.abs(got["pose"] - ref["pose"]).max() < 1e-8
+    eng.close()
+
+
 def test_rollout_equals_repeated_single_launches(env):
     chain = env.robots.lwr()
     B, K, dt = 4096, 25, 0.004
