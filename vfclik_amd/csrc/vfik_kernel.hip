@@ -659,6 +659,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             R[3 * r + 1] = tc * y - ts * x;
         }
     }
+    // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
+    // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's passes over the Jacobian.
+    constexpr bool FUSEP = NULLSP && NJ >= 8;
+    double zp[FUSEP ? NJ : 1];
+    if constexpr (FUSEP) {
+        const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) zp[i] = 0.0;
+        if (jlt) {  // -jl_gain (q - mid) / half^2; constants fetched together under the one uniform branch
+            double jk[NJ], qm[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { jk[i] = kc->jl_k[i]; qm[i] = kc->q_mid[i]; }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) zp[i] = -jk[i] * (q[i] - qm[i]);
+        }
+    }
+    // ACCJ (long chains, unit weights): J J^T and J z are accumulated here, while each Jacobian column is still in
+    // VGPRs on its way into the AGPRs the Jacobian lives in at these sizes -- one pass of 168 register moves less.
+    constexpr bool ACCJ = NJ >= 8 && PLAIN;
+    double Ae[ACCJ ? 6 : 1][6], wne[6];
+    if constexpr (ACCJ) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            wne[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Ae[r][c] = 0.0;
+        }
+    }
     // geometric Jacobian at the flange, base frame
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -666,6 +694,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
             const double cx = Jm[i][4] * dz - Jm[i][5] * dy, cy = Jm[i][5] * dx - Jm[i][3] * dz,
                          cz = Jm[i][3] * dy - Jm[i][4] * dx;
+            if constexpr (ACCJ) {
+                const double col[6] = {cx, cy, cz, Jm[i][3], Jm[i][4], Jm[i][5]};
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) Ae[ACCJ ? r : 0][c] = __builtin_fma(col[r], col[c], Ae[ACCJ ? r : 0][c]);
+                    if constexpr (FUSEP) wne[r] = __builtin_fma(col[r], zp[FUSEP ? i : 0], wne[r]);
+                }
+            }
             if (PLAIN) {
                 Jm[i][0] = cx; Jm[i][1] = cy; Jm[i][2] = cz;
             } else {
@@ -711,12 +748,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // working set early and leaves only the two triangular solves after the field.  Measured neutral on
     // C3 (7.05-7.14 us per launch either way): the pivot chain is not what the wave waits for.
     constexpr bool EARLY_FACTOR = NJ <= 7;
-    // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
-    // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's two passes over the Jacobian -- G = J J^T
-    // and J z are accumulated with A, and J^T w is subtracted while J^T y is formed -- because for n = 14
-    // the Jacobian lives in AGPRs and every further pass costs 168 register moves.
-    constexpr bool FUSEP = NULLSP && NJ >= 8;
-    double zp[FUSEP ? NJ : 1];
+    // (FUSEP: G = J J^T and J z are accumulated with A, and J^T w is subtracted while J^T y is formed -- for n = 14
+    // the Jacobian lives in AGPRs and every further pass costs 168 register moves.)
     const double* wts = (!PLAIN && a.wts) ? a.wts + arm : nullptr;
     const long wpitch = a.Bpad;
     double Sw[PLAIN ? 1 : NJ][6];
@@ -744,42 +777,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
-        if constexpr (FUSEP) {
-            const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) zp[i] = 0.0;
-            if (jlt) {  // -jl_gain (q - mid) / half^2; constants fetched together under the one uniform branch
-                double jk[NJ], qm[NJ];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) { jk[i] = kc->jl_k[i]; qm[i] = kc->q_mid[i]; }
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) zp[i] = -jk[i] * (q[i] - qm[i]);
-            }
+        if constexpr (ACCJ) {  // accumulated with the Jacobian columns above
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                wn[r] = 0.0;
+                wn[r] = wne[r];
 #pragma unroll
-                for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
+                for (int c = 0; c <= r; ++c) A[r][c] = Ae[ACCJ ? r : 0][c];
+                if constexpr (!GFROMA) A[r][r] += kc->lambda2;
             }
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
+            for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
+                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
+            if constexpr (FUSEP) {
 #pragma unroll
-                for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
-                if constexpr (FUSEP) {
-                    wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
-                    if constexpr (!PLAIN) {
+                for (int r = 0; r < 6; ++r) {
+                    wn[r] = 0.0;
 #pragma unroll
-                        for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
-                    }
+                    for (int c = 0; c <= r; ++c) G[r][c] = 0.0;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
+                    if constexpr (FUSEP) {
+                        wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
+                        if constexpr (!PLAIN) {
+#pragma unroll
+                            for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
+                        }
+                    }
+                }
+        }
         if constexpr (GFROMA) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
