@@ -540,12 +540,13 @@ def test_lean_kernel_variant_only_qdot_out(env, robot, dt, flags):
     params = env.abi.default_params(flags=flags, max_vel=0.7)
     eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
     eng.set_fields(w["fields"], w["nfields"])
-    lean = eng.step_host(w["q"], want=("qdot_out",))
+    lean = eng.step_host(w["q"], want=("qdot_out", "status"))  # status is part of the LEAN variant too
     eng.reset_state()
     full = eng.step_host(w["q"], want=("qdot_out", "status", "pose"))
     ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"])
     tol = TOL64 if dt == np.float64 else 2e-6
     assert np.abs(lean["qdot_out"] - ref["qdot_out"]).max() < tol
+    assert np.array_equal(lean["status"], ref["status"])
     assert np.abs(lean["qdot_out"].astype(np.float64) - full["qdot_out"]).max() < (1e-12 if dt == np.float64 else 5e-7)
     eng.close()
 

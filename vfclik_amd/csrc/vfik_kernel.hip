@@ -466,7 +466,8 @@ template <typename T> struct SlotLds {
 // ROLL = closed-loop rollout: a.n_cycles control cycles in one launch, the joint angles
 // integrated in registers (q += dt * qdot_out, the role of the external joint_sim, vfclik:99-103), the
 // field set read from LDS every cycle; one launch boundary and one set of loads per n_cycles cycles.
-// LEAN = nothing but q -> qdot_out: no optional input or output (and, without the nullspace module, no feature flag):
+// LEAN = nothing but q -> qdot_out (and status, which is free): no other optional input or output (and, without the
+// nullspace module, no feature flag):
 // the BASELINE C3 and C5 launches.  The arguments that select those options are compile-time nulls, so their code is
 // not in the kernel at all -- present but never executed, it cost the C3 launch 4.5 % (6.47 -> 6.18 us, same box).
 // amdgpu_waves_per_eu(1, 1): one wave per SIMD is what the launch gets anyway (registers, LDS); telling the backend
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
         a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
         a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
-        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status = nullptr; a.status_or = 0;
+        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status_or = 0;
         if constexpr (!ROLL) a.q_out = nullptr;  // (a rollout's q_out is its result)
     }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
@@ -1597,7 +1598,7 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     bool lean = false;
     if constexpr (PL)
         lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.ext && !a.q_ref && !a.q_cmded &&
-               !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.status;
+               !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
             if constexpr (PL) {
