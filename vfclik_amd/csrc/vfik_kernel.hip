@@ -547,10 +547,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     constexpr int N_SLOT = 2 * PRE * Q16;                   // requests issued after the goal
     // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
     // slot quads are requested into that wait, the remaining slot quads between the joints.
-#ifndef VFIK_EARLY_Q
-#define VFIK_EARLY_Q 6
-#endif
-    constexpr int EARLY_Q = VFIK_EARLY_Q;
+    // (long chains have two rows of constants and five q pieces in front already: nothing early there, C5 -1.3 %)
+    constexpr int EARLY_Q = NJ >= 10 ? 0 : 6;
     constexpr int SLOTQ_PER_JOINT = (2 * PRE - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
 #pragma unroll
     for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
