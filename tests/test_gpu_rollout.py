@@ -67,10 +67,16 @@ def test_lean_rollout_only_q_and_qdot_out(env, robot, dt_io, flags):
     eng = env.engine.Engine(chain, B, io_dtype=dt_io, max_slots=8, params=params)
     eng.set_fields(w["fields"], w["nfields"])
     got = eng.rollout_host(w["q"], K, dt, clamp=True, want=("qdot_out",))
-    q_ref, ref, _ = _oracle_rollout(env, chain, params, w, K, dt, None, clamp=True)
+    q_ref, ref, st_ref = _oracle_rollout(env, chain, params, w, K, dt, None, clamp=True)
     tol_q, tol_v = (1e-8, 1e-7) if dt_io == np.float64 else (2e-6, 2e-5)
     assert np.abs(got["q"] - q_ref).max() < tol_q, np.abs(got["q"] - q_ref).max()
     assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < tol_v
+    # the same with the status bits, which accumulate over the cycles (also over the launches of a stepped rollout)
+    eng.reset_state()
+    got = eng.rollout_host(w["q"], K, dt, clamp=True, want=("qdot_out", "status"))
+    assert np.abs(got["q"] - q_ref).max() < tol_q
+    if dt_io == np.float64:
+        assert np.array_equal(got["status"], st_ref)
     eng.close()
 
 

@@ -472,15 +472,16 @@ template <typename T> struct SlotLds {
 // not in the kernel at all -- present but never executed, it cost the C3 launch 4.5 % (6.47 -> 6.18 us, same box).
 // amdgpu_waves_per_eu(1, 1): one wave per SIMD is what the launch gets anyway (registers, LDS); telling the backend
 // lets its scheduler stop trading instruction order for a register count it cannot use (C3 -2.4 %, same-box A/B).
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, bool LEAN>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) cycle_kernel(const KArgs a_in) {
     KArgs a = a_in;
-    if constexpr (LEAN) {
+    if constexpr (LEAN != 0) {  // 1: lean, 2: lean with q_out kept (one cycle of a stepped rollout, long chains)
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
         a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
         a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
-        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.status_or = 0;
-        if constexpr (!ROLL) a.q_out = nullptr;  // (a rollout's q_out is its result)
+        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr;
+        if constexpr (LEAN == 1) a.status_or = 0;  // (a stepped rollout accumulates the status bits of its cycles)
+        if constexpr (!ROLL && LEAN == 1) a.q_out = nullptr;  // (a rollout's q_out is its result)
     }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
@@ -1601,23 +1602,29 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         if (a.n_cycles > 0) {
             if constexpr (PL) {
                 if (lean) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, true>), grid, blk, lds, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 1>), grid, blk, lds, stream, a);
                     return;
                 }
             }
-            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, false>), grid, blk, lds, stream, a);
-            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, false>), grid, blk, lds, stream, a);
+            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 0>), grid, blk, lds, stream, a);
+            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, 0>), grid, blk, lds, stream, a);
             return;
         }
     }
     if constexpr (PL) {
         if (lean && !a.q_out) {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, true>), grid, blk, lds, stream, a);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds, stream, a);
             return;
         }
+        if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
+            if (lean) {
+                hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds, stream, a);
+                return;
+            }
+        }
     }
-    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, false>), grid, blk, lds, stream, a);
-    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, false>), grid, blk, lds, stream, a);
+    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 0>), grid, blk, lds, stream, a);
+    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, 0>), grid, blk, lds, stream, a);
 }
 
 template <typename T, int NJ>
