@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the batched control cycle (BASELINE.json metric: 7-DOF IK cycles/s at batch 65 536).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,9 +10,17 @@ synthetic inputs that are already resident in HBM.  Workload at every N: BASELIN
 (65 536 arms x 7 joints, goal + 8 decay repellers, float32 I/O, float64 arithmetic) -- C4 is exactly
 this with 8 ranks, so scaling is weak and there is no collective on the data path.
 
+Timing (median and p10/p90): the timed region -- barrier, synchronize, stamp, EXACTLY K
+launches, synchronize, stamp -- is repeated R times (--reps); the collective that takes the maximum over
+ranks runs after the last repetition, outside every stamped interval.  `value` comes from the MEDIAN
+repetition; p10/p90 are printed next to it.  HIP events on the launch stream bracket the same K launches of
+every repetition and give the kernel's launch period for `roofline`.
+
 Rank 0 prints one JSON line.  `roofline` prices the kernel against HBM with the ALGORITHMIC bytes of
-SURVEY 8d (384 B per cycle at C3); `cpu_baseline` times the CPU oracle (oracle/, the build's port of
-the reference loop -- the reference itself cannot run) on this box's host cores.
+SURVEY 8d (384 B per cycle at C3); `cpu_baseline` (N = 1 only) times the CPU oracle (oracle/, the build's
+port of the reference loop -- the reference itself cannot run) on this box's host cores, BEFORE
+this process touches the GPU: the reference-style per-arm NumPy loop as one process per core over disjoint
+arm slices (kind "port"), and the C/OpenMP port as `best_cpu`.
 """
 import argparse
 import json
@@ -39,16 +47,95 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(chain, params, w, budget_s=12.0):
-    """CPU oracle (C, OpenMP over arms) on repeated passes over the same batch, ~budget_s seconds."""
-    from oracle import oracle_c
-    threads = oracle_c.max_threads()
+def host_cores(cap=16):
+    """Worker processes / threads for the CPU baseline: the cores this process may use -- its cpuset, the
+    cgroup's CPU quota when one is set -- and at most `cap`: a 1-GPU box is a 16-core share of a host whose
+    other cores (os.cpu_count() reports them all) belong to other tenants; oversubscribing them measured
+    5e5 cycles/s for the C port on 256 threads against 8.5e6 on an idle 128."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, (quota + period // 2) // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap) if cap else n)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (checker code timed as a baseline: the only place besides tests/ and smoke() that uses oracle/)
+# ---------------------------------------------------------------------------------------------------
+def _numpy_slice_worker(args):
+    """One process of the reference-style loop: one arm per Python iteration, exactly like the loop of
+    scripts/vf:193-521 minus sleeps and ports (oracle/vfik_numpy.ArmCycle), over its own slice of arms,
+    pass after pass until the budget is used up."""
+    chain, pd, q, fields, nfields, budget_s = args
+    from oracle import vfik_numpy as vn
+    from vfclik_amd import _abi
+    try:  # one core per process: the 6 x 6 solves must not start a BLAS thread pool each
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except ImportError:
+        pass
+    arms = []
+    for b in range(q.shape[0]):
+        arm = vn.ArmCycle(chain.B, chain.jtype, chain.q_lo, chain.q_hi, pd)
+        arm.set_fields({int(f["id"]): [float(f["force"]), int(f["type"]), f["p"][:_abi.FIELD_NPARAMS[int(f["type"])]].tolist()]
+                        for f in fields[b][: nfields[b]]})
+        arms.append((arm, q[b].tolist()))
+    cycles = 0
+    t0 = time.perf_counter()
+    while True:
+        for arm, qb in arms:
+            arm.cycle(qb)
+        cycles += len(arms)
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            return cycles, dt
+
+
+def numpy_loop_node_rate(chain, params, w, procs, arms_per_proc=64, budget_s=6.0):
+    """SURVEY 8d CPU baseline (1): `procs` independent processes over disjoint arm slices -> whole-node
+    cycles/s = all cycles / the slowest process's time.  Runs before the GPU is initialised (fork is safe)."""
+    import multiprocessing as mp
+    from vfclik_amd import _abi
+    pd = _abi.params_to_dict(params)
     B = w["q"].shape[0]
-    oracle_c.cycle_batch(chain, params, w["q"][:1024], w["fields"][:1024], w["nfields"][:1024], want=("qdot_out",))
+    per = max(1, min(arms_per_proc, B // procs))
+    jobs = [(chain, pd, w["q"][p * per:(p + 1) * per], w["fields"][p * per:(p + 1) * per], w["nfields"][p * per:(p + 1) * per], budget_s)
+            for p in range(procs)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_numpy_slice_worker, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    cycles = sum(c for c, _ in res)
+    slowest = max(t for _, t in res)
+    return {"value": cycles / slowest, "unit": "cycles/s", "cores": procs, "kind": "port",
+            "sample": "reference-style per-arm NumPy loop (oracle/vfik_numpy.ArmCycle = scripts/vf:193-521 minus sleeps and ports): "
+                      "%d processes x %d arms each (disjoint slices of the bench batch), repeated passes for %.1f s; %d cycles, wall %.1f s incl. process start"
+                      % (procs, per, slowest, cycles, wall),
+            "per_process_cycles_per_s": cycles / slowest / procs}
+
+
+def c_oracle_rate(chain, params, w, threads, budget_s=8.0):
+    """CPU baseline (2), "best CPU": the C port of the oracle, OpenMP over arms, repeated passes over the batch."""
+    from oracle import oracle_c
+    threads = max(1, min(threads, oracle_c.max_threads()))
+    B = w["q"].shape[0]
+    oracle_c.cycle_batch(chain, params, w["q"][:1024], w["fields"][:1024], w["nfields"][:1024], want=("qdot_out",), nthreads=threads)
     t0 = time.perf_counter()
     passes = 0
     while True:
-        oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",))
+        oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",), nthreads=threads)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s and passes >= 2:
@@ -57,48 +144,77 @@ def cpu_baseline(chain, params, w, budget_s=12.0):
             "sample": "%d passes over the %d-arm batch in %.1f s, C oracle (oracle/vfik_oracle.c), OpenMP" % (passes, B, dt)}
 
 
-def numpy_loop_rate(chain, params, w, arms=150):
-    """The reference-style per-arm Python/NumPy loop (oracle/vfik_numpy.py), one process."""
-    from oracle import vfik_numpy as vn
-    from vfclik_amd import _abi
-    pd = _abi.params_to_dict(params)
-    cycles = []
-    for b in range(arms):
-        arm = vn.ArmCycle(chain.B, chain.jtype, chain.q_lo, chain.q_hi, pd)
-        arm.set_fields({int(f["id"]): [float(f["force"]), int(f["type"]), f["p"][:_abi.FIELD_NPARAMS[int(f["type"])]].tolist()]
-                        for f in w["fields"][b][: w["nfields"][b]]})
-        cycles.append((arm, w["q"][b].tolist()))
-    t0 = time.perf_counter()
-    for arm, q in cycles:
-        arm.cycle(q)
-    return arms / (time.perf_counter() - t0)
+def pctl(xs, p):
+    xs = sorted(xs)
+    if len(xs) == 1:
+        return xs[0]
+    k = (len(xs) - 1) * p / 100.0
+    lo = int(k)
+    hi = min(lo + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=30, help="repetitions of the timed region (K steps each); value = median repetition")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes / threads of the CPU baseline (0 = this box's CPU share, at most 16)")
     ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
     ap.add_argument("--host-path", type=int, default=100, help="also time this many steps with q/qdot in host memory (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the real thing; gloo + --single-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--sync-each", action="store_true",
+                    help="diagnostic: synchronize after every launch (un-overlapped kernel durations for a rocprofv3 kernel trace); "
+                         "the line is then not a throughput measurement")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
-    from vfclik_amd import _abi, engine, robots, synth
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.reps < 1 or args.warmup < 0:
+        raise SystemExit("--gpus, --steps, --reps must be >= 1 and --warmup >= 0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no external launcher: this process becomes the parent of one fresh process per GPU.  It has made
+        # no GPU call (torch is not even imported yet) and makes none afterwards.
+        from vfclik_amd import launcher
+        raise SystemExit(launcher.main_spawn(os.path.abspath(__file__), sys.argv[1:] if argv is None else argv, args.gpus))
+    return worker(args)
+
+
+def worker(args):
+    from vfclik_amd import _abi, robots, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    robot, B, nobs, io_name, flags, bytes_per_cycle = WORKLOADS[args.workload]
+    io_dtype = np.dtype(io_name)
+    chain = robots.by_name(robot)
+    params = _abi.default_params(flags=flags)
+    w = synth.make_workload(chain, B, nobs, seed=1 + rank, io_dtype=io_dtype.type)  # SURVEY 8d: seeds 1.. for timing
+
+    # CPU baseline first, while this process has not initialised the GPU (rank 0 at N = 1 only)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cores = args.cpu_procs if args.cpu_procs > 0 else host_cores()
+        cpu = numpy_loop_node_rate(chain, params, w, procs=cores)
+        cpu["os_cpu_count"] = os.cpu_count()
+        cpu["best_cpu"] = c_oracle_rate(chain, params, w, cores)
+
+    import torch
+    import torch.distributed as dist
+
+    from vfclik_amd import engine
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if args.single_device:
@@ -111,12 +227,6 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    robot, B, nobs, io_name, flags, bytes_per_cycle = WORKLOADS[args.workload]
-    io_dtype = np.dtype(io_name)
-    chain = robots.by_name(robot)
-    params = _abi.default_params(flags=flags)
-    w = synth.make_workload(chain, B, nobs, seed=1 + rank, io_dtype=io_dtype.type)  # SURVEY 8d: seeds 1.. for timing
-
     eng = engine.Engine(chain, B, io_dtype=io_dtype.type, max_slots=nobs, device=local_rank, params=params)
     eng.set_fields(w["fields"], w["nfields"])
     tdt = torch.float32 if io_dtype == np.float32 else torch.float64
@@ -128,28 +238,50 @@ def main():
     eng.use_stream(stream.cuda_stream)
     io = eng.make_io(q, qdot_out=qdot)
 
-    def sync_all():
+    def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+
+    def reduce_max(values):
+        """element-wise maximum over the ranks of a list of floats (one collective, outside every stamped interval)"""
+        if world == 1:
+            return list(values)
+        t = torch.tensor(values, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
 
     for _ in range(args.warmup):
         eng.step(io)
-    sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        eng.step(io)
-    enqueue_s = time.perf_counter() - t0  # host time to issue the launches (must stay below the kernel time)
-    ev1.record(stream)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)  # same stream as the launches
+    torch.cuda.synchronize()
+
+    K, R = args.steps, args.reps
+    wall_s, ev_pairs, enqueue_s = [], [], []
+    for _ in range(R):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()                      # ranks start together; the barrier itself is NOT inside the interval
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(K):
+            eng.step(io)
+            if args.sync_each:
+                torch.cuda.synchronize()
+        t_enq = time.perf_counter()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        wall_s.append(t1 - t0)
+        enqueue_s.append(t_enq - t0)
+        ev_pairs.append((ev0, ev1))
+    ev_ms = [a.elapsed_time(b) for a, b in ev_pairs]  # same stream as the launches
+    own_wall_s = list(wall_s)
+    wall_s = reduce_max(wall_s)        # per repetition: the slowest rank
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([pctl(own_wall_s, 50) * 1e3 / K], dtype=torch.float64, device=red_dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank_ms = [float(p.item()) for p in parts]
 
     # secondary figure (never `value`): closed-loop rollout, K control cycles per launch with q integrated in
     # registers (SURVEY 8f-4) -- what the cycle costs once the per-launch boundary is amortised
@@ -159,19 +291,16 @@ def main():
         qd2 = torch.empty_like(qdot)
         io_r = eng.make_io(q, qdot_out=qd2)
         eng.rollout(io_r, args.rollout, 1e-3, q_out=q_end)
-        sync_all()
+        torch.cuda.synchronize()
         launches = 5
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
         r0.record(stream)
         for _ in range(launches):
             eng.rollout(io_r, args.rollout, 1e-3, q_out=q_end)
         r1.record(stream)
-        sync_all()
-        r_ms = r0.elapsed_time(r1)
-        if world > 1:
-            t = torch.tensor([r_ms], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            r_ms = float(t.item())
+        torch.cuda.synchronize()
+        r_ms = reduce_max([r0.elapsed_time(r1)])[0]
         rollout = {"cycles_per_launch": args.rollout, "launches": launches, "dt": 1e-3,
                    "us_per_cycle": r_ms * 1e3 / (launches * args.rollout),
                    "cycles_per_s": world * B * launches * args.rollout / (r_ms * 1e-3)}
@@ -215,26 +344,31 @@ def main():
 
     if rank == 0:
         got = qdot.cpu().numpy().astype(np.float64)
-        from oracle import oracle_c  # checker only: accuracy half of the metric + CPU baseline
+        from oracle import oracle_c  # checker only: accuracy half of the metric
         ref = oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",))
         max_err = float(np.abs(got - ref["qdot_out"]).max())
-        us_per_launch = ev_ms * 1e3 / args.steps
-        achieved = bytes_per_cycle * B / (us_per_launch * 1e-6) / 1e9
-        traffic = None
+        med_s, p10_s, p90_s = pctl(wall_s, 50), pctl(wall_s, 10), pctl(wall_s, 90)
+        us_launch = [m * 1e3 / K for m in ev_ms]
+        us_med = pctl(us_launch, 50)
+        achieved = bytes_per_cycle * B / (us_med * 1e-6) / 1e9
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(args.workload, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command, round %s; not measured by this run)" % rec.get("round")
             except Exception:
                 traffic = None
+        total = world * B * K
         line = {
             "metric": "7-DOF IK cycles/sec (whole node), batch=65536; max |qdot-qdot_ref|",
-            "value": world * B * args.steps / elapsed,
+            "value": total / med_s,
             "unit": "cycles/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step": med_s * 1e3 / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -244,31 +378,43 @@ def main():
                                    % (args.workload, B, chain.n, chain.name, nobs, io_name, flags),
                        "parallelism": "arm batch sharded over %d GPU(s), no collective" % world,
                        "lambda": params.lambda_, "launches_per_step": 1,
-                       "host_enqueue_us_per_step": enqueue_s * 1e6 / args.steps},
+                       "host_enqueue_us_per_step": pctl(enqueue_s, 50) * 1e6 / K},
+            "repetitions": {"count": R, "steps_each": K, "value_p10": total / p90_s, "value_median": total / med_s, "value_p90": total / p10_s,
+                            "ms_per_step_p10": p10_s * 1e3 / K, "ms_per_step_median": med_s * 1e3 / K, "ms_per_step_p90": p90_s * 1e3 / K,
+                            "timed": "per repetition: barrier, synchronize, stamp, K launches, synchronize, stamp; max over ranks per repetition; "
+                                     "no collective inside a stamped interval"},
             "max_abs_err_rad_s": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN>: the bench
                          # workloads (revolute chain, identity tool, unit weights, integer-order repellers, qdot_out only)
-                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true,true>" % ("float" if io_name == "float32" else "double", chain.n,
-                                                                                   "true" if flags & 1 else "false"),
-                         "algorithmic_bytes_per_cycle": bytes_per_cycle, "us_per_launch_hip_events": us_per_launch},
+                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true,1>" % ("float" if io_name == "float32" else "double", chain.n,
+                                                                                "true" if flags & 1 else "false"),
+                         "algorithmic_bytes_per_cycle": bytes_per_cycle,
+                         "us_per_launch_hip_events": us_med,
+                         "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),
+                         "launches_timed": R * K},
         }
+        if args.sync_each:
+            line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"
+        if per_rank_ms is not None:
+            line["per_rank_ms_per_step"] = per_rank_ms
         if rollout is not None:
             line["rollout"] = rollout
         if host_path is not None:
             line["host_path"] = host_path
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(chain, params, w)
-            line["cpu_baseline"]["numpy_ref_style_loop_cycles_per_s_1proc"] = numpy_loop_rate(chain, params, w)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         if gathered is not None:
             line["config"]["gathered_rows"] = int(gathered.shape[0])
         print(json.dumps(line), flush=True)
 
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VFIK_ABI_VERSION 2
+#define VFIK_ABI_VERSION 3
 
 enum {
     VFIK_OK = 0,
@@ -127,6 +127,8 @@ typedef struct vfik_io {
     void* goal_dist;          /* out [B][2]   xyz distance and rotation angle in DEGREES to the goal: the object-0
                                  entry of /dmonitor/distOut (monitor_distance:76-84,161-172) */
     const void* q_ref;        /* in  [B][n]   /jpctrl/ref (joint_p_controller:113-118); NULL = no joint controller.
+                                 An arm whose row starts with NaN has no controller either: its channel 2 stays the
+                                 external /bridge/jointcmd command of vfik_set_ext_cmd.
                                  With VFIK_F_MIXER the controller's output kp*(clamp(ref,limits) - q)
                                  (joint_p_controller:89-99,124-128) IS mixer channel 2 (/bridge/jointcmd,
                                  joint_p_controller:78) and an external channel-2 command is not read */
@@ -134,6 +136,20 @@ typedef struct vfik_io {
                                  NULL = velocity command.  With it qdot_out is the LWR command form
                                  -q_cmded + q + qdot_lim (bridge:199-203) unless all mixer weights of the arm
                                  are 0 ("direct_control", bridge:604).  vfik_step only */
+    /* ---- ABI 3 ---- */
+    const int32_t* active;    /* in  [B]      fresh-q gate, NULL = every arm.  The reference advances an arm only when that
+                                 arm's own joint angles arrived (vf:312-313, nullspace:162-163, debug_jointlimits:61): an
+                                 arm with active[b] == 0 publishes NOTHING this cycle -- no output row of it is written
+                                 (status included) and its nullspace sign memory (nullspace:91-92) stays as it was */
+    const void* q_lo;         /* in  [B][n]   joint limits of THIS cycle, per arm; NULL (both) = the chain's static limits. */
+    const void* q_hi;         /*              The reference re-reads the limits every cycle because some robots' limits
+                                 depend on the configuration (nullspace:167 `rob.get_limits()`, joint_p_controller:80
+                                 `config.updateJntLimits(cur_pos)`, :121-125).  Used by check_limits (nullspace:120-131), the
+                                 joint controller's clamp (joint_p_controller:79-89), distToCenter (debug_jointlimits:66-67),
+                                 the joint-limit task and the rollout's clamp.  lo < hi is the caller's business */
+    void* q_ref_out;          /* out [B][n]   the joint controller's reference after its clamp: the reference KEEPS the clamped
+                                 value (joint_p_controller:121 `ref = check_limits(ref, indata)`), so with limits that move
+                                 a host feeds this back as the next cycle's q_ref.  Only with q_ref */
 } vfik_io;
 
 /* One control cycle for the whole batch -- the loop bodies of vf:311-466, nullspace:162-184,
@@ -175,8 +191,10 @@ int vfik_rollout_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt
  * poses and field twists that vfik_step produced (device pointers pose[B][16], v6[B][6]); out[B][8] gets
  * vel_diff_angle, rot_diff_angle, ext_vel_mag_corr, ext_rot_mag_corr, cmd_vel_mag_corr, cmd_rot_mag_corr,
  * ext_int_diff, arm_tracking (the /track_error bottle, vf:418-427); zeros until the 6th frame (vf:354).
- * Per-arm history (previous frame, last 4 commands) lives in the handle; vfik_track_reset clears it. */
-int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out);
+ * Per-arm history (previous frame, last 4 commands) lives in the handle; vfik_track_reset clears it.
+ * active[B] (device, may be NULL = every arm): the estimator sits inside vf's `if qInBottle` block (vf:312-313,349),
+ * so an arm without fresh joint angles appends no frame and no command -- its history and its out row stay. */
+int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out, const int32_t* active);
 int vfik_track_reset(vfik_handle* h);
 
 /* Field probe of scripts/vf (vf:469-503, /pose_in -> /vector_out, "for visualizing"): every arm's field set
