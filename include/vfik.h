@@ -96,7 +96,8 @@ int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double
 
 /* Per-arm mixer weights, w[n_arms][6]: what each arm's bridge keeps after a /bridge/weight message
  * (command_mixer.py:48-53; handlers send [cart, null, joint, 0], handlers.py:189-204).  NULL returns every
- * arm to the batch-wide vfik_params.mix_w. */
+ * arm's weights to the batch-wide vfik_params.mix_w (per-arm limiter speeds of vfik_set_max_vel stay).  A
+ * vfik_set_params that CHANGES vfik_params.mix_w writes the new weights to every arm. */
 int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w);
 
 /* Per-arm limiter speed: what each arm's bridge keeps after a /bridge/max_vel message (bridge:612-623; the

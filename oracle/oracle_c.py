@@ -42,9 +42,11 @@ def new_states(B, n):
 
 
 def cycle_batch(chain, params, q, fields, nfields, tool=None, null_control=None, ext_cmd=None, states=None,
-                want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status"), nthreads=0):
+                want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status"), nthreads=0,
+                q_lo=None, q_hi=None, active=None, into=None):
     """chain: vfclik_amd.chain.Chain; params: _abi.Params; q (B,n) f64; fields (B,M) FIELD_DTYPE;
-    nfields (B,) i32; tool (16,) or (B,16); ext_cmd (4,B,n).  Returns dict of arrays."""
+    nfields (B,) i32; tool (16,) or (B,16); ext_cmd (4,B,n); q_lo / q_hi (B,n): this cycle's limits per arm;
+    active (B,): arms with 0 are skipped (rows of `into`, a dict from an earlier call, stay).  Returns dict of arrays."""
     L = lib()
     q = np.ascontiguousarray(q, dtype=np.float64)
     B, n = q.shape
@@ -62,15 +64,19 @@ def cycle_batch(chain, params, q, fields, nfields, tool=None, null_control=None,
         states = new_states(B, n)
     shapes = {"qdot_vf": (B, n), "qdot_null": (B, n), "qdot_out": (B, n), "pose": (B, 16), "pose_nt": (B, 16),
               "v6": (B, 6), "qdist": (B, n)}
-    out = {k: np.zeros(s) for k, s in shapes.items() if k in want}
+    out = {k: (into[k] if into is not None and k in into else np.zeros(s)) for k, s in shapes.items() if k in want}
     if "status" in want:
-        out["status"] = np.zeros(B, dtype=np.int32)
+        out["status"] = into["status"] if into is not None and "status" in into else np.zeros(B, dtype=np.int32)
+    lo = None if q_lo is None else np.ascontiguousarray(q_lo, dtype=np.float64)
+    hi = None if q_hi is None else np.ascontiguousarray(q_hi, dtype=np.float64)
+    assert (lo is None) == (hi is None) and (lo is None or (lo.shape == (B, n) and hi.shape == (B, n)))
+    act = None if active is None else np.ascontiguousarray(np.asarray(active) != 0, dtype=np.int32)
     cs = chain.to_struct()
     L.vfo_cycle_batch(C.byref(cs), C.byref(params), C.c_int(B), _p(tool), C.c_int(tstride), _p(fields), C.c_int(M),
                       _p(nfields), _p(q), _p(nc), _p(ec), states if states is not None else None,
                       _p(out.get("qdot_vf")), _p(out.get("qdot_null")), _p(out.get("qdot_out")), _p(out.get("pose")),
                       _p(out.get("pose_nt")), _p(out.get("v6")), _p(out.get("qdist")), _p(out.get("status")),
-                      C.c_int(nthreads))
+                      C.c_int(nthreads), _p(lo), _p(hi), _p(act))
     out["states"] = states
     return out
 

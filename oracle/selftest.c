@@ -77,7 +77,7 @@ int main(void) {
     vfik_field none[3];
     memset(none, 0, sizeof none);
     int cnt[3] = {0, 0, 0};
-    vfo_cycle_batch(&c, &p, 3, tool, 0, none, 1, cnt, q, 0, 0, 0, 0, 0, out, 0, 0, 0, 0, 0, 2);
+    vfo_cycle_batch(&c, &p, 3, tool, 0, none, 1, cnt, q, 0, 0, 0, 0, 0, out, 0, 0, 0, 0, 0, 2, 0, 0, 0);
     for (int i = 0; i < 21; ++i) if (out[i] != 0.0) { printf("empty field set moved\n"); ++fails; }
     printf(fails ? "FAILED %d\n" : "selftest OK\n", fails);
     return fails != 0;

@@ -534,13 +534,21 @@ void vfo_cycle_batch(const vfik_chain* c, const vfik_params* p, int B, const dou
                      const double* q, const double* null_control, const double* ext_cmd,
                      vfo_state* st, double* qdot_vf, double* qdot_null, double* qdot_out,
                      double* pose, double* pose_nt, double* v6, double* qdist, int* status,
-                     int nthreads) {
+                     int nthreads, const double* q_lo, const double* q_hi, const int* active) {
     const int n = c->n;
     (void)nthreads;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
 #endif
     for (int b = 0; b < B; ++b) {
+        if (active && !active[b]) continue; /* `if qInBottle` (vf:312-313): no fresh joint angles, no cycle */
+        vfik_chain cb;                      /* this cycle's limits of this arm (nullspace:167) */
+        const vfik_chain* ca = c;
+        if (q_lo && q_hi) {
+            cb = *c;
+            for (int k = 0; k < n; ++k) { cb.q_lo[k] = q_lo[(long)b * n + k]; cb.q_hi[k] = q_hi[(long)b * n + k]; }
+            ca = &cb;
+        }
         double ext[4 * MAXJ];
         if (ext_cmd)
             for (int ch = 0; ch < 4; ++ch)
@@ -554,7 +562,7 @@ void vfo_cycle_batch(const vfik_chain* c, const vfik_params* p, int B, const dou
         o.v6 = v6 ? v6 + (long)b * 6 : 0;
         o.qdist = qdist ? qdist + (long)b * n : 0;
         o.status = status ? status + b : 0;
-        vfo_cycle(c, p, tool + (long)b * tool_stride, fields + (long)b * max_fields, nfields[b],
+        vfo_cycle(ca, p, tool + (long)b * tool_stride, fields + (long)b * max_fields, nfields[b],
                   q + (long)b * n, null_control ? null_control + (long)b * VFIK_NULL_CONTROLS : 0,
                   ext_cmd ? ext : 0, st ? st + b : 0, &o);
     }

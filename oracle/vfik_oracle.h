@@ -83,13 +83,17 @@ void vfo_cycle(const vfik_chain* c, const vfik_params* p, const double tool[16],
 
 /* batch driver (OpenMP over arms when built with -fopenmp).  All arrays are batch-major AoS:
  * q[B][n], tool[B][16] (tool_stride 0 = shared), fields[B][max_fields], nfields[B],
- * null_control[B][4] or NULL, ext_cmd[4][B][n] or NULL, outputs [B][..] or NULL. */
+ * null_control[B][4] or NULL, ext_cmd[4][B][n] or NULL, outputs [B][..] or NULL.
+ * q_lo / q_hi [B][n] or NULL: the arm's joint limits of THIS cycle, which the reference re-reads every cycle
+ * (nullspace:167 rob.get_limits(), joint_p_controller:80 config.updateJntLimits(cur_pos)); NULL = the chain's.
+ * active[B] or NULL: an arm with active[b] == 0 got no joint angles this cycle -- its loop body does not run
+ * (vf:312-313, nullspace:162-163, debug_jointlimits:61): no output row written, state untouched. */
 void vfo_cycle_batch(const vfik_chain* c, const vfik_params* p, int B, const double* tool,
                      int tool_stride, const vfik_field* fields, int max_fields, const int* nfields,
                      const double* q, const double* null_control, const double* ext_cmd,
                      vfo_state* st, double* qdot_vf, double* qdot_null, double* qdot_out,
                      double* pose, double* pose_nt, double* v6, double* qdist, int* status,
-                     int nthreads);
+                     int nthreads, const double* q_lo, const double* q_hi, const int* active);
 int vfo_max_threads(void);
 
 #ifdef __cplusplus

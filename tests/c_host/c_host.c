@@ -103,7 +103,7 @@ int main(void) {
     CHECK(vfik_step_host(h, &io));
     vfo_state* states = malloc(sizeof(vfo_state) * NB);
     for (int b = 0; b < NB; ++b) vfo_state_init(&states[b], NJ);
-    vfo_cycle_batch(&chain, &p, NB, tool, 0, fields, NF, counts, q, ctrl, NULL, states, NULL, NULL, ref, pose_ref, NULL, NULL, NULL, st_ref, 0);
+    vfo_cycle_batch(&chain, &p, NB, tool, 0, fields, NF, counts, q, ctrl, NULL, states, NULL, NULL, ref, pose_ref, NULL, NULL, NULL, st_ref, 0, NULL, NULL, NULL);
     double worst = 0.0, worst_pose = 0.0;
     int bad_status = 0;
     for (int k = 0; k < NB * NJ; ++k) worst = fmax(worst, fabs(got[k] - ref[k]));
@@ -132,7 +132,7 @@ int main(void) {
     memcpy(qs, q, sizeof(double) * NB * NJ);
     for (int b = 0; b < NB; ++b) vfo_state_init(&states[b], NJ);
     for (int t = 0; t < K; ++t) { /* the oracle stepped on the host, joint_sim integration in between */
-        vfo_cycle_batch(&chain, &p, NB, tool, 0, fields, NF, counts, qs, NULL, NULL, states, NULL, NULL, ref, NULL, NULL, NULL, NULL, NULL, 0);
+        vfo_cycle_batch(&chain, &p, NB, tool, 0, fields, NF, counts, qs, NULL, NULL, states, NULL, NULL, ref, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL);
         for (int b = 0; b < NB; ++b)
             for (int i = 0; i < NJ; ++i) {
                 double v = fma(dt, ref[b * NJ + i], qs[b * NJ + i]);

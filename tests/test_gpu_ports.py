@@ -357,3 +357,85 @@ def test_pose_in_probe_and_goal_out(net):
     assert np.abs(seen_goal[1][:16] - goal).max() == 0.0 and seen_goal[1][16] == 0.1
     cc.close()
     feeder.close()
+
+
+def test_a_silent_arm_keeps_its_state_through_the_ports(net):
+    """Two arms behind the ports; the second gets no joint angles for 10 cycles (its robot is late).  What it then
+    publishes -- /nullspace/qdotout with its sign memory (nullspace:91-107), /track_error with its 5-frame history
+    (vf:350-356) -- equals a single-arm module that only ever saw the cycles in which its q arrived
+    (vf:312-313, nullspace:162-163); while silent it publishes nothing.  An arm that has no joint-controller
+    reference yet still mixes what arrives on /bridge/jointcmd while its neighbour's controller runs."""
+    yarp = net
+    from vfclik_amd import robots
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    clock = [10.0]
+    two = ControlCycleBatch(chain, ["/0/lwr/a", "/0/lwr/b"], io_dtype=np.float64, clock=lambda: clock[0])
+    one = ControlCycleBatch(chain, ["/1/lwr/b"], io_dtype=np.float64, clock=lambda: clock[0])
+    rng = np.random.default_rng(12)
+    goal = chain.fk(rng.uniform(0.4 * chain.q_lo, 0.4 * chain.q_hi, (1, 7))).reshape(16)
+
+    def wire(prefix, arm):
+        base = "/%s/lwr/%s" % (prefix, arm)
+        d = {"enc": _open(yarp, "/t%s%s/enc" % (prefix, arm)), "par": _open(yarp, "/t%s%s/par" % (prefix, arm), True),
+             "ctl": _open(yarp, "/t%s%s/ctl" % (prefix, arm)), "w": _open(yarp, "/t%s%s/w" % (prefix, arm), True),
+             "jc": _open(yarp, "/t%s%s/jc" % (prefix, arm)),
+             "null": _open(yarp, "/t%s%s/null" % (prefix, arm)), "te": _open(yarp, "/t%s%s/te" % (prefix, arm)),
+             "mixed": _open(yarp, "/t%s%s/mixed" % (prefix, arm))}
+        yarp.Network.connect(d["enc"].getName(), base + "/vectorField/qIn")
+        yarp.Network.connect(d["par"].getName(), base + "/vectorField/param")
+        yarp.Network.connect(d["ctl"].getName(), base + "/nullspace/control")
+        yarp.Network.connect(d["w"].getName(), base + "/bridge/weight")
+        yarp.Network.connect(d["jc"].getName(), base + "/bridge/jointcmd")
+        yarp.Network.connect(base + "/nullspace/qdotout", d["null"].getName())
+        yarp.Network.connect(base + "/vectorField/track_error", d["te"].getName())
+        yarp.Network.connect(base + "/bridge/mixed", d["mixed"].getName())
+        b = d["par"].prepare()
+        b.clear()
+        b.add("add"); b.add(1); b.add(1.0); b.add(1); b.add([float(x) for x in goal] + [0.1])
+        d["par"].writeStrict()
+        _send(d["w"], [1.0, 1.0, 0.5, 0.0])  # the joint channel counts
+        return d
+
+    A, Bm, S = wire("0", "a"), wire("0", "b"), wire("1", "b")
+    ref_port = _open(yarp, "/t/jpref")
+    yarp.Network.connect("/t/jpref", "/0/lwr/a/jpctrl/ref")
+    _send(ref_port, np.zeros(7))  # arm a's joint controller gets a reference; arm b never does
+    qa = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, 7)
+    qb = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, 7)
+    jcmd = rng.normal(size=7)
+    published = compared_te = 0
+    for t in range(26):
+        clock[0] += 0.01
+        silent = 6 <= t < 16
+        _send(A["enc"], qa)
+        for d in (Bm, S):
+            _send(d["ctl"], [0.8, 0, 0, 0])
+            _send(d["jc"], jcmd)       # external joint command of arm b (no controller there)
+        if not silent:
+            _send(Bm["enc"], qb)
+            _send(S["enc"], qb)
+        got = two.cycle()
+        assert got[0] and got[1] == (not silent)
+        if not silent:
+            assert one.cycle()[0]
+        nb, ns = _read(Bm["null"]), _read(S["null"])
+        tb, ts = _read(Bm["te"]), _read(S["te"])
+        mb, ms = _read(Bm["mixed"]), _read(S["mixed"])
+        if silent:
+            assert nb is None and tb is None and mb is None  # nothing published (vf:312-313)
+            qa = qa + 0.01 * rng.normal(size=7)
+            continue
+        published += 1
+        assert np.abs(nb - ns).max() < 1e-12 and np.abs(mb - ms).max() < 1e-12
+        assert (tb is None) == (ts is None)
+        if tb is not None:
+            compared_te += 1
+            assert np.abs(tb - ts).max() < 1e-12
+        # arm b turns by a big step, so that a sign memory advanced with stale q would pick the other sign
+        qb = np.clip(qb + 0.15 * rng.normal(size=7), 0.9 * chain.q_lo, 0.9 * chain.q_hi)
+        qa = qa + 0.01 * rng.normal(size=7)
+    assert published == 16 and compared_te >= 8
+    assert np.abs(mb).max() > 0.1
+    two.close()
+    one.close()

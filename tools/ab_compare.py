@@ -21,8 +21,9 @@ def run(lib, workload):
     env.pop("VFIK_HIP_LIB", None)
     if lib:
         env["VFIK_HIP_LIB"] = os.path.abspath(lib)
+        env["VFIK_AB_ALLOW_OLDER_ABI"] = "1"  # a build of an earlier ABI can still run the bench workloads
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--no-cpu-baseline", "--host-path", "0",
-                          "--rollout", "0"], env=env, capture_output=True, text=True, timeout=300)
+                          "--rollout", "0", "--steps", "200", "--reps", "30"], env=env, capture_output=True, text=True, timeout=300)
     d = json.loads(out.stdout.strip().split("\n")[-1])
     return d["roofline"]["us_per_launch_hip_events"], d["max_abs_err_rad_s"]
 

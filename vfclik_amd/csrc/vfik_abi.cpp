@@ -84,12 +84,12 @@ struct vfik_handle {
     bool speed_set = false;
     // scratch for vfik_step_host
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
-    Scratch sc[14];
+    Scratch sc[20];
     // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
     // its own device staging buffers and events; s_in / s_out are the side streams
     static constexpr int PIPE = 3;
     struct PipeSlot {
-        Scratch sc[14];
+        Scratch sc[20];
         hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
         long ticket = -1;  // submission living in this slot, -1 = free
     };
@@ -205,6 +205,10 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.qdist = io->qdist;
     a.status = io->status;
     a.goal_dist = io->goal_dist;
+    a.active = io->active;
+    a.q_lo = io->q_lo;
+    a.q_hi = io->q_hi;
+    a.q_ref_out = io->q_ref ? io->q_ref_out : nullptr;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -387,10 +391,17 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p) {
     for (int k = 0; k < 6; ++k) weights_changed = weights_changed || p->wy[k] != h->params.wy[k];
     for (int k = 0; k < h->n; ++k) weights_changed = weights_changed || p->wq[k] != h->params.wq[k];
     const bool maxvel_changed = p->max_vel != h->params.max_vel;
+    bool mixw_changed = false;
+    for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mixw_changed = mixw_changed || p->mix_w[k] != h->params.mix_w[k];
     h->params = *p;
-    if (maxvel_changed && h->d_mixw_arm) {  // vfik_params.max_vel is batch-wide: written to every arm, like speed_scale
+    if ((maxvel_changed || mixw_changed) && h->d_mixw_arm) {
+        // vfik_params.max_vel / mix_w are batch-wide: a CHANGED value is written to every arm, like speed_scale
+        // (with per-arm bridge state the kernel reads nothing else)
         HIP_TRY(hipSetDevice(h->device));
-        for (int b = 0; b < h->B; ++b) h->bridge_host[(size_t)b * 8 + 6] = p->max_vel;
+        for (int b = 0; b < h->B; ++b) {
+            if (maxvel_changed) h->bridge_host[(size_t)b * 8 + 6] = p->max_vel;
+            for (int k = 0; mixw_changed && k < VFIK_MIX_CHANNELS; ++k) h->bridge_host[(size_t)b * 8 + k] = p->mix_w[k];
+        }
         const int rc = upload_bridge_state(h, 0, h->B);
         if (rc != VFIK_OK) return rc;
     }
@@ -578,11 +589,11 @@ int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const doub
     if (check_handle(h)) return VFIK_E_ARG;
     if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     HIP_TRY(hipSetDevice(h->device));
-    if (!w) {  // back to the batch-wide values of vfik_params (mixer weights and limiter max_vel)
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->d_mixw_arm) { HIP_TRY(hipFree(h->d_mixw_arm)); h->d_mixw_arm = nullptr; }
-        h->bridge_host.clear();
-        return VFIK_OK;
+    if (!w) {  // every arm's mixer weights back to the batch-wide vfik_params.mix_w; per-arm limiter speeds stay
+        if (!h->d_mixw_arm) return VFIK_OK;
+        for (int b = 0; b < h->B; ++b)
+            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) h->bridge_host[(size_t)b * 8 + k] = h->params.mix_w[k];
+        return upload_bridge_state(h, 0, h->B);
     }
     if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
     if (ensure_bridge_state(h) != VFIK_OK) return VFIK_E_HIP;
@@ -637,6 +648,7 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     if (!h->chain_set) return fail(VFIK_E_STATE, "vfik_set_chain has not been called");
     if (n_cycles > 0 && io->q_cmded) return fail(VFIK_E_ARG, "io->q_cmded (LWR position command form) is for vfik_step only");
+    if (!io->q_lo != !io->q_hi) return fail(VFIK_E_ARG, "io->q_lo and io->q_hi come together (both or neither)");
     HIP_TRY(hipSetDevice(h->device));
     vfik::KArgs a;
     fill_kargs(h, io, a);
@@ -660,7 +672,7 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
             k.q_out = (last && q_out) ? q_out : h->d_rollq[c & 1];
             k.status_or = c > 0;
             if (!last) {  // intermediate cycles produce no outputs but the status bits
-                k.qdot_vf = k.qdot_null = k.qdot_out = k.pose = k.pose_nt = k.v6 = k.qdist = k.goal_dist = nullptr;
+                k.qdot_vf = k.qdot_null = k.qdot_out = k.pose = k.pose_nt = k.v6 = k.qdist = k.goal_dist = k.q_ref_out = nullptr;
             }
             hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, k, h->block, stream);
             if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -690,16 +702,38 @@ int vfik_sync(vfik_handle* h) {
     return VFIK_OK;
 }
 
+// host-pointer forms: which vfik_io members are inputs / outputs, and their sizes in bytes
+namespace {
+constexpr int N_HIN = 7, N_HOUT = 11;
+struct HostIo {
+    const void* hin[N_HIN];
+    size_t bin[N_HIN];
+    void* hout[N_HOUT];
+    size_t bout[N_HOUT];
+};
+HostIo host_io(const vfik_handle* h, const vfik_io* io, void* q_out_host) {
+    const size_t B = h->B, n = h->n, e = h->esz;
+    HostIo x{{io->q, io->null_control, io->q_ref, io->q_cmded, io->active, io->q_lo, io->q_hi},
+             {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e, B * sizeof(int32_t), B * n * e, B * n * e},
+             {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host, io->goal_dist,
+              io->q_ref ? io->q_ref_out : nullptr},
+             {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e, B * n * e}};
+    return x;
+}
+void device_io(void* const* din, void* const* dout, vfik_io& d) {
+    d = vfik_io{};
+    d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
+    d.active = static_cast<const int32_t*>(din[4]); d.q_lo = din[5]; d.q_hi = din[6];
+    d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
+    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[9]; d.q_ref_out = dout[10];
+}
+}  // namespace
+
 static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out_host) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     HIP_TRY(hipSetDevice(h->device));
-    const size_t B = h->B, n = h->n, e = h->esz;
-    const void* hin[4] = {io->q, io->null_control, io->q_ref, io->q_cmded};
-    const size_t bin[4] = {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e};
-    static const int in_slot[4] = {0, 1, 12, 13};
-    void* hout[10] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host, io->goal_dist};
-    const size_t bout[10] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e};
+    const HostIo x = host_io(h, io, q_out_host);
     auto need = [&](int i, size_t bytes) -> void* {
         auto& s = h->sc[i];
         if (s.bytes < bytes) {
@@ -710,26 +744,26 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
         }
         return s.p;
     };
-    void* din[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 4; ++i)
-        if (hin[i]) {
-            din[i] = need(in_slot[i], bin[i]);
+    void* din[N_HIN] = {};
+    for (int i = 0; i < N_HIN; ++i)
+        if (x.hin[i]) {
+            din[i] = need(i, x.bin[i]);
             if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
-            HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(din[i], x.hin[i], x.bin[i], hipMemcpyHostToDevice, h->stream));
         }
-    void* dout[10];
-    for (int i = 0; i < 10; ++i) {
-        dout[i] = hout[i] ? need(2 + i, bout[i]) : nullptr;
-        if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+    void* dout[N_HOUT];
+    for (int i = 0; i < N_HOUT; ++i) {
+        dout[i] = x.hout[i] ? need(N_HIN + i, x.bout[i]) : nullptr;
+        if (x.hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+        // gated arms store nothing: their rows of the caller's arrays must come back as they went in
+        if (x.hout[i] && io->active) HIP_TRY(hipMemcpyAsync(dout[i], x.hout[i], x.bout[i], hipMemcpyHostToDevice, h->stream));
     }
-    vfik_io d{};
-    d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
-    d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
-    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[9];
+    vfik_io d;
+    device_io(din, dout, d);
     const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
-    for (int i = 0; i < 10; ++i)
-        if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->stream));
+    for (int i = 0; i < N_HOUT; ++i)
+        if (x.hout[i]) HIP_TRY(hipMemcpyAsync(x.hout[i], dout[i], x.bout[i], hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
 }
@@ -789,11 +823,7 @@ int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket) {
         HIP_TRY(hipEventSynchronize(ps.ev_out));
         ps.ticket = -1;
     }
-    const size_t B = h->B, n = h->n, e = h->esz;
-    const void* hin[4] = {io->q, io->null_control, io->q_ref, io->q_cmded};
-    const size_t bin[4] = {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e};
-    void* hout[9] = {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, io->goal_dist};
-    const size_t bout[9] = {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * 2 * e};
+    const HostIo x = host_io(h, io, nullptr);
     auto need = [&](int i, size_t bytes) -> void* {
         auto& sc = ps.sc[i];
         if (sc.bytes < bytes) {
@@ -810,8 +840,8 @@ int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket) {
     // copy engine instead, which overlaps that kernel: 56 us per step at 2-3 in flight, against 66 us for
     // reads by the kernel and 95 us for the three-stream staging below.
     bool direct = true;
-    for (int i = 0; i < 4 && direct; ++i) direct = !hin[i] || gpu_visible(hin[i]);
-    for (int i = 0; i < 9 && direct; ++i) direct = !hout[i] || gpu_visible(hout[i]);
+    for (int i = 0; i < N_HIN && direct; ++i) direct = !x.hin[i] || gpu_visible(x.hin[i]);
+    for (int i = 0; i < N_HOUT && direct; ++i) direct = !x.hout[i] || gpu_visible(x.hout[i]);
     if (direct) {
         bool busy = false;
         for (auto& o : h->pipe)
@@ -819,14 +849,16 @@ int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket) {
         (void)hipGetLastError();
         vfik_io d = *io;
         if (busy) {
-            const void** din[4] = {&d.q, &d.null_control, &d.q_ref, &d.q_cmded};
-            for (int i = 0; i < 4; ++i)
-                if (hin[i]) {
-                    void* dp = need(i, bin[i]);
+            void* din[N_HIN] = {};
+            for (int i = 0; i < N_HIN; ++i)
+                if (x.hin[i]) {
+                    void* dp = need(i, x.bin[i]);
                     if (!dp) return fail(VFIK_E_HIP, "staging allocation failed");
-                    HIP_TRY(hipMemcpyAsync(dp, hin[i], bin[i], hipMemcpyHostToDevice, h->s_in));
-                    *din[i] = dp;
+                    HIP_TRY(hipMemcpyAsync(dp, x.hin[i], x.bin[i], hipMemcpyHostToDevice, h->s_in));
+                    din[i] = dp;
                 }
+            d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
+            d.active = static_cast<const int32_t*>(din[4]); d.q_lo = din[5]; d.q_hi = din[6];
             HIP_TRY(hipEventRecord(ps.ev_in, h->s_in));
             HIP_TRY(hipStreamWaitEvent(h->stream, ps.ev_in, 0));
         }
@@ -837,28 +869,29 @@ int vfik_submit_host(vfik_handle* h, const vfik_io* io, long* ticket) {
         *ticket = h->next_ticket++;
         return VFIK_OK;
     }
-    void* din[4] = {nullptr, nullptr, nullptr, nullptr};
-    void* dout[9];
-    for (int i = 0; i < 4; ++i)
-        if (hin[i] && !(din[i] = need(i, bin[i]))) return fail(VFIK_E_HIP, "staging allocation failed");
-    for (int i = 0; i < 9; ++i) {
-        dout[i] = hout[i] ? need(4 + i, bout[i]) : nullptr;
-        if (hout[i] && !dout[i]) return fail(VFIK_E_HIP, "staging allocation failed");
+    void* din[N_HIN] = {};
+    void* dout[N_HOUT];
+    for (int i = 0; i < N_HIN; ++i)
+        if (x.hin[i] && !(din[i] = need(i, x.bin[i]))) return fail(VFIK_E_HIP, "staging allocation failed");
+    for (int i = 0; i < N_HOUT; ++i) {
+        dout[i] = x.hout[i] ? need(N_HIN + i, x.bout[i]) : nullptr;
+        if (x.hout[i] && !dout[i]) return fail(VFIK_E_HIP, "staging allocation failed");
     }
-    for (int i = 0; i < 4; ++i)
-        if (hin[i]) HIP_TRY(hipMemcpyAsync(din[i], hin[i], bin[i], hipMemcpyHostToDevice, h->s_in));
+    for (int i = 0; i < N_HIN; ++i)
+        if (x.hin[i]) HIP_TRY(hipMemcpyAsync(din[i], x.hin[i], x.bin[i], hipMemcpyHostToDevice, h->s_in));
+    if (io->active)  // gated arms store nothing: their rows must come back as they went in
+        for (int i = 0; i < N_HOUT; ++i)
+            if (x.hout[i]) HIP_TRY(hipMemcpyAsync(dout[i], x.hout[i], x.bout[i], hipMemcpyHostToDevice, h->s_in));
     HIP_TRY(hipEventRecord(ps.ev_in, h->s_in));
     HIP_TRY(hipStreamWaitEvent(h->stream, ps.ev_in, 0));
-    vfik_io d{};
-    d.q = din[0]; d.null_control = din[1]; d.q_ref = din[2]; d.q_cmded = din[3];
-    d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
-    d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[8];
+    vfik_io d;
+    device_io(din, dout, d);
     const int rc = vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
     HIP_TRY(hipEventRecord(ps.ev_k, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->s_out, ps.ev_k, 0));
-    for (int i = 0; i < 9; ++i)
-        if (hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bout[i], hipMemcpyDeviceToHost, h->s_out));
+    for (int i = 0; i < N_HOUT; ++i)
+        if (x.hout[i]) HIP_TRY(hipMemcpyAsync(x.hout[i], dout[i], x.bout[i], hipMemcpyDeviceToHost, h->s_out));
     HIP_TRY(hipEventRecord(ps.ev_out, h->s_out));
     ps.ticket = h->next_ticket;
     *ticket = h->next_ticket++;
@@ -872,12 +905,12 @@ int vfik_track_reset(vfik_handle* h) {
     return VFIK_OK;
 }
 
-int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out) {
+int vfik_track_error(vfik_handle* h, const void* pose, const void* v6, void* out, const int32_t* active) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!pose || !v6 || !out) return fail(VFIK_E_ARG, "vfik_track_error: pose, v6 and out are required");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->d_track && dev_alloc(h, (void**)&h->d_track, (size_t)38 * h->B * sizeof(double), true)) return VFIK_E_HIP;
-    hipError_t e = vfik::launch_track(h->io_dtype, pose, v6, h->d_track, out, h->B, h->stream);
+    hipError_t e = vfik::launch_track(h->io_dtype, pose, v6, h->d_track, out, active, h->B, h->stream);
     if (e != hipSuccess) return fail(VFIK_E_HIP, "track launch: %s", hipGetErrorString(e));
     return VFIK_OK;
 }

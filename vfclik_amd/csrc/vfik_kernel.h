@@ -56,6 +56,7 @@ struct KConst {
     double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
     double cos_slow;  // cos(rot_slow): rotation angles with a smaller cosine need no atan2 (scalar = 1)
     double jp_kp, jp_delta;  // joint P controller (joint_p_controller:55-57)
+    double jl_gain;          // gain of the joint-limit task (jl_k is jl_gain / half^2 of the STATIC limits; per-cycle limits use this)
     unsigned prismatic_mask;
     unsigned pad0;
     static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
@@ -105,6 +106,11 @@ struct KArgs {
     int n_cycles;                // 0: ordinary single-cycle launch
     int clamp;                   // keep q inside [q_lo, q_hi] after each integration step
     int status_or;               // OR the status bits into what a.status already holds (cycle 2.. of a stepped rollout)
+    // ABI 3
+    const int* active;           // [B] fresh-q gate (vf:312-313, nullspace:162-163): 0 = the arm stores nothing this launch; NULL = all
+    const void* q_lo;            // [B][n] this cycle's joint limits per arm (nullspace:167, joint_p_controller:80), or NULL:
+    const void* q_hi;            //        the chain's static limits of KConst
+    void* q_ref_out;             // [B][n] the joint controller's reference after its clamp (joint_p_controller:121), or NULL
 };
 
 // size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest
@@ -119,7 +125,7 @@ hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hip
 hipError_t launch_probe(int io_dtype, const void* pose, const void* goal, const void* slots, int B, long Bp, int slots_used,
                         double rot_slow, double cos_slow, void* out, hipStream_t stream);
 hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream);
-hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, int B, hipStream_t stream);
+hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, const int* active, int B, hipStream_t stream);
 hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K, long count, long chan_stride,
                       void* out, hipStream_t stream);
 

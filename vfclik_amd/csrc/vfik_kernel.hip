@@ -480,6 +480,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
         a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
         a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr;
+        a.active = nullptr; a.q_lo = nullptr; a.q_hi = nullptr; a.q_ref_out = nullptr;
         if constexpr (LEAN == 1) a.status_or = 0;  // (a stepped rollout accumulates the status bits of its cycles)
         if constexpr (!ROLL && LEAN == 1) a.q_out = nullptr;  // (a rollout's q_out is its result)
     }
@@ -512,6 +513,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             __builtin_amdgcn_global_load_lds((GPtr)(kg + r * 1024), (LPtr)(region + Stage<T>::kin_off(NJ) + r * 1024), 16, 0, 0);
     }
     if (arm >= a.B) return;
+    // Fresh-q gate (vf:312-313, nullspace:162-163): an arm whose joint angles did not arrive this cycle stores
+    // nothing.  Requested first, consumed at the stores: every counted wait below covers this oldest request.
+    int act = 1;
+    if (a.active) act = a.active[arm];
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
@@ -597,6 +602,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         asm volatile("" : "+v"(lanec));
         asm volatile("" : "+s"(kc));  // nor SGPRs for ~70 hoisted scalar constants (they would spill through VGPR lanes)
     }
+    // Joint limits of this cycle: the arm's own (io.q_lo / q_hi; nullspace:167 and joint_p_controller:80 re-read
+    // them every cycle) or the chain's.  Fetched where they are used, all joints in one go.
+    auto limits_of = [&](double* lo, double* hi) {
+        if (a.q_lo) {
+            const T* l = static_cast<const T*>(a.q_lo) + (long)arm * NJ;
+            const T* h = static_cast<const T*>(a.q_hi) + (long)arm * NJ;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { lo[i] = (double)l[i]; hi[i] = (double)h[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { lo[i] = kc->q_lo[i]; hi[i] = kc->q_hi[i]; }
+        }
+    };
+    // z = -jl_gain (q - mid) / half^2, the descent direction of the joint-limit potential
+    auto jl_descent = [&](double* z) {
+        if (a.q_lo) {
+            double lo[NJ], hi[NJ];
+            limits_of(lo, hi);
+            const double g = kc->jl_gain;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const double ih = rcp_nr(0.5 * (hi[i] - lo[i]));
+                z[i] = -g * (q[i] - 0.5 * (lo[i] + hi[i])) * ih * ih;
+            }
+        } else {  // constants fetched together under the one uniform branch
+            double jk[NJ], qm[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) { jk[i] = kc->jl_k[i]; qm[i] = kc->q_mid[i]; }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) z[i] = -jk[i] * (q[i] - qm[i]);
+        }
+    };
     const bool first = !ROLL || cyc == 0;
     if (ROLL && !first && a.slots_used > PRE) {  // the rows hold the last chunk of the previous cycle
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -667,13 +704,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) zp[i] = 0.0;
-        if (jlt) {  // -jl_gain (q - mid) / half^2; constants fetched together under the one uniform branch
-            double jk[NJ], qm[NJ];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) { jk[i] = kc->jl_k[i]; qm[i] = kc->q_mid[i]; }
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) zp[i] = -jk[i] * (q[i] - qm[i]);
-        }
+        if (jlt) jl_descent(zp);
     }
     // ACCJ (long chains, unit weights): J J^T and J z are accumulated here, while each Jacobian column is still in
     // VGPRs on its way into the AGPRs the Jacobian lives in at these sizes -- one pass of 168 register moves less.
@@ -1224,17 +1255,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
                 }
                 if constexpr (!ROLL) {
-                    a.sig[arm] = sig_r;
+                    if (act) {
+                        a.sig[arm] = sig_r;
     #pragma unroll
-                    for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
+                        for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
+                    }
                 }
             } else if (nullity >= 2) {
                 status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
             }
             if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
                 double z[NJ];
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);  // -jl_gain (q - mid) / half^2
+                jl_descent(z);
     #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     double c = 0.0;
@@ -1258,8 +1290,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // the test is bit arithmetic: written with `||` it became a chain of branches, each with its own
         // scalar load and wait (~200 cycles a joint).
         double lo[NJ], hi[NJ];
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) { lo[i] = kc->q_lo[i]; hi[i] = kc->q_hi[i]; }
+        limits_of(lo, hi);
         const double look = kc->lookahead, ngain = kc->null_gain;
         int bad = 0;
 #pragma unroll
@@ -1293,9 +1324,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (a.q_ref) {  // joint P controller -> /bridge/jointcmd = channel 2 (joint_p_controller:78,89-99,124-128)
             const T* rf = static_cast<const T*>(a.q_ref) + (long)arm * NJ;
             double rlo[NJ], rhi[NJ];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) { rlo[i] = kc->q_lo[i]; rhi[i] = kc->q_hi[i]; }
+            limits_of(rlo, rhi);
             const double delta = kc->jp_delta, kp = kc->jp_kp;
+            // a NaN in the row's first element: this arm has no joint controller, its channel 2 is the external command
+            const double rv0 = (double)rf[0];
+            const bool ctl = rv0 == rv0;
+            const T* e2 = a.ext ? static_cast<const T*>(a.ext) + (long)arm * NJ : nullptr;
+            T* ro = (a.q_ref_out && act && (!ROLL || cyc == ncyc - 1)) ? static_cast<T*>(a.q_ref_out) + (long)arm * NJ : nullptr;
             int far = 0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
@@ -1303,9 +1338,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const double ref = rv < rlo[i] ? rlo[i] : (rv > rhi[i] ? rhi[i] : rv);
                 const double err = ref - q[i];
                 far |= (int)!(err < delta);  // signed, as joint_p_controller:135 compares it
-                qo[i] = mac_unfused(qo[i], err * kp, mw[2]);
+                const double other = e2 ? (double)e2[i] : 0.0;
+                qo[i] = mac_unfused(qo[i], ctl ? err * kp : other, mw[2]);
+                if (ro) ro[i] = (T)(ctl ? ref : rv);  // the controller keeps the clamped reference (joint_p_controller:121)
             }
-            if (!far) status |= VFIK_ST_JOINT_AT_GOAL;
+            if (!far && ctl) status |= VFIK_ST_JOINT_AT_GOAL;
         }
         if (a.ext) {
             const T* e = static_cast<const T*>(a.ext);
@@ -1340,7 +1377,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int i = 0; i < NJ; ++i) nan |= (int)(qo[i] != qo[i]);
     if (nan) status |= VFIK_ST_NAN;
 
-    if (!ROLL || cyc == ncyc - 1) {  // the outputs are those of the last evaluated cycle
+    if ((!ROLL || cyc == ncyc - 1) && act) {  // the outputs are those of the last evaluated cycle
         // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
         if (a.qdot_out) {
             T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
@@ -1390,9 +1427,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         if (a.qdist) {
             T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
+            if (a.q_lo) {
+                double lo[NJ], hi[NJ];
+                limits_of(lo, hi);
     #pragma unroll
-            for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
-
+                for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - 0.5 * (lo[i] + hi[i])) * rcp_nr(0.5 * (hi[i] - lo[i])));
+            } else {
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+            }
         }
         if (a.goal_dist) {  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
             T* o = static_cast<T*>(a.goal_dist) + (long)arm * 2;
@@ -1405,13 +1448,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int i = 0; i < NJ; ++i) q[i] = __builtin_fma(a.dt, qo[i], q[i]);
         if (a.clamp) {  // one uniform branch, the limits fetched together (not a load and a wait per joint)
             double lo[NJ], hi[NJ];
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) { lo[i] = kc->q_lo[i]; hi[i] = kc->q_hi[i]; }
+            limits_of(lo, hi);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) q[i] = fmin(fmax(q[i], lo[i]), hi[i]);
         }
     }
     }  // cycles of this launch
+    if (!act) return;  // (no store has been made for this arm)
     if constexpr (NULLSP && ROLL && NJ <= 7) {
         a.sig[arm] = sig_r;
 #pragma unroll
@@ -1448,9 +1491,10 @@ __global__ void __launch_bounds__(256) mix_kernel(const T* cmds, const double* w
 // cmd_vel_mag_corr, cmd_rot_mag_corr, ext_int_diff, arm_tracking (vf:418-427); zeros until the 6th frame.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) track_kernel(const T* pose, const T* v6, double* st, T* out, int B) {
+__global__ void __launch_bounds__(256) track_kernel(const T* pose, const T* v6, double* st, T* out, const int* active, int B) {
     const int arm = blockIdx.x * blockDim.x + threadIdx.x;
     if (arm >= B) return;
+    if (active && !active[arm]) return;  // inside vf's `if qInBottle` (vf:312-313,349): no fresh q, no new frame
     const long Bs = B;
     double F[12], P[12], cmd[4][6];
 #pragma unroll
@@ -1597,7 +1641,8 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     bool lean = false;
     if constexpr (PL)
         lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.ext && !a.q_ref && !a.q_cmded &&
-               !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist;
+               !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.active && !a.q_lo &&
+               !a.q_ref_out;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
             if constexpr (PL) {
@@ -1760,6 +1805,7 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.max_vel = p.max_vel;
     c.jp_kp = p.jp_kp;
     c.jp_delta = p.jp_delta;
+    c.jl_gain = p.jl_gain;
     // PLAIN variant of the kernel: revolute joints only, no trailing screw, identity tool, unit weights
     bool pl = c.prismatic_mask == 0 && c.tail_c == 1.0 && c.tail_s == 0.0 && c.tail_e == 0.0;
     static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -1848,15 +1894,15 @@ hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, in
     return hipGetLastError();
 }
 
-hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, int B, hipStream_t stream) {
+hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, const int* active, int B, hipStream_t stream) {
     const int block = 256;
     const dim3 grid((B + block - 1) / block), blk(block);
     if (io_dtype == 32)
         hipLaunchKernelGGL(track_kernel<float>, grid, blk, 0, stream, static_cast<const float*>(pose), static_cast<const float*>(v6),
-                           state, static_cast<float*>(out), B);
+                           state, static_cast<float*>(out), active, B);
     else
         hipLaunchKernelGGL(track_kernel<double>, grid, blk, 0, stream, static_cast<const double*>(pose),
-                           static_cast<const double*>(v6), state, static_cast<double*>(out), B);
+                           static_cast<const double*>(v6), state, static_cast<double*>(out), active, B);
     return hipGetLastError();
 }
 }  // namespace vfik

@@ -21,11 +21,12 @@ class IO(C.Structure):
     _fields_ = [("q", C.c_void_p), ("null_control", C.c_void_p), ("qdot_vf", C.c_void_p), ("qdot_null", C.c_void_p),
                 ("qdot_out", C.c_void_p), ("pose", C.c_void_p), ("pose_nt", C.c_void_p), ("v6", C.c_void_p),
                 ("qdist", C.c_void_p), ("status", C.c_void_p), ("goal_dist", C.c_void_p),
-                ("q_ref", C.c_void_p), ("q_cmded", C.c_void_p)]
+                ("q_ref", C.c_void_p), ("q_cmded", C.c_void_p),
+                ("active", C.c_void_p), ("q_lo", C.c_void_p), ("q_hi", C.c_void_p), ("q_ref_out", C.c_void_p)]
 
 
 _OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n",
-               "goal_dist": 2}
+               "goal_dist": 2, "q_ref_out": "n"}
 _lib = None
 
 
@@ -69,7 +70,7 @@ def load_library(path=None):
         "vfik_rollout": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
         "vfik_rollout_host": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_double, C.c_int, C.c_void_p]),
         "vfik_mix": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-        "vfik_track_error": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "vfik_track_error": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "vfik_track_reset": (C.c_int, [H]),
         "vfik_dev_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_dev_free": (C.c_int, [H, C.c_void_p]),
@@ -91,12 +92,15 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
         fn.restype = res
         fn.argtypes = args
-    if lib.vfik_abi_version() != 2:
+    # tools/ab_compare.py times an OLDER build against this one through bench.py: an ABI-2 library reads a prefix of
+    # the ABI-3 vfik_io and is never handed the new members there.  Nothing else may set this.
+    older_ok = os.environ.get("VFIK_AB_ALLOW_OLDER_ABI") == "1" and path != _abi.HIP_LIB_PATH
+    if lib.vfik_abi_version() != 3 and not (older_ok and lib.vfik_abi_version() == 2):
         raise VfikError("ABI version mismatch")
     sizes = (C.c_size_t * 4)()
     lib.vfik_struct_sizes(sizes)
     mine = [C.sizeof(_abi.Field), C.sizeof(_abi.Chain), C.sizeof(_abi.Params), C.sizeof(IO)]
-    if list(sizes) != mine:
+    if list(sizes) != mine and not (older_ok and list(sizes)[:3] == mine[:3]):
         raise VfikError("struct layout mismatch: library %s, Python mirrors %s" % (list(sizes), mine))
     if path == _abi.HIP_LIB_PATH or _lib is None:
         _lib = lib
@@ -224,15 +228,38 @@ class Engine:
         d = _OUT_SHAPES[key]
         return (self.batch, self.n if d == "n" else d)
 
-    def step_host(self, q, null_control=None, want=("qdot_out",), q_ref=None, q_cmded=None):
+    def _host_inputs(self, io, keep, active=None, q_lo=None, q_hi=None):
+        """The ABI-3 inputs of a host-array call: fresh-q gate and this cycle's per-arm joint limits."""
+        if (q_lo is None) != (q_hi is None):
+            raise ValueError("q_lo and q_hi come together")
+        if active is not None:
+            a = np.ascontiguousarray(np.asarray(active) != 0, dtype=np.int32)
+            if a.shape != (self.batch,):
+                raise ValueError("active must be (%d,), got %s" % (self.batch, a.shape))
+            io.active = a.ctypes.data
+            keep.append(a)
+        for name, arr in (("q_lo", q_lo), ("q_hi", q_hi)):
+            if arr is not None:
+                a = np.ascontiguousarray(arr, dtype=self.io_dtype)
+                if a.shape != (self.batch, self.n):
+                    raise ValueError("%s must be (%d, %d), got %s" % (name, self.batch, self.n, a.shape))
+                setattr(io, name, a.ctypes.data)
+                keep.append(a)
+
+    def step_host(self, q, null_control=None, want=("qdot_out",), q_ref=None, q_cmded=None, active=None, q_lo=None, q_hi=None,
+                  into=None):
         """Host arrays in, host arrays out (copies + sync inside the library).  q_ref: /jpctrl/ref of the
-        joint P controller (mixer channel 2); q_cmded: the LWR's commanded-position echo (bridge:199-203)."""
+        joint P controller (mixer channel 2); q_cmded: the LWR's commanded-position echo (bridge:199-203);
+        active: fresh-q gate (B,) -- arms with 0 publish nothing and keep their state (vf:312-313); q_lo / q_hi:
+        this cycle's joint limits per arm (nullspace:167).  `into`: a dict of arrays from an earlier call to write
+        into (rows of gated arms then keep their previous content instead of zeros)."""
         q = np.ascontiguousarray(q, dtype=self.io_dtype)
         if q.shape != (self.batch, self.n):
             raise ValueError("q must be (%d, %d), got %s" % (self.batch, self.n, q.shape))
         io = IO()
         io.q = q.ctypes.data
         keep = [q]
+        self._host_inputs(io, keep, active, q_lo, q_hi)
         for name, arr in (("q_ref", q_ref), ("q_cmded", q_cmded)):
             if arr is not None:
                 a = np.ascontiguousarray(arr, dtype=self.io_dtype)
@@ -248,7 +275,10 @@ class Engine:
             keep.append(nc)
         out = {}
         for k in want:
-            if k == "status":
+            if into is not None and k in into:
+                out[k] = into[k]
+                self._check_host(k, out[k], (self.batch,) if k == "status" else self._shape(k), np.int32 if k == "status" else self.io_dtype)
+            elif k == "status":
                 out[k] = np.zeros(self.batch, dtype=np.int32)
             else:
                 out[k] = np.zeros(self._shape(k), dtype=self.io_dtype)
@@ -298,7 +328,8 @@ class Engine:
     def wait(self, ticket):
         self._chk(self.lib.vfik_wait(self.h, int(ticket)))
 
-    def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",), q_ref=None):
+    def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",), q_ref=None, active=None, q_lo=None,
+                     q_hi=None):
         """n_cycles control cycles in one launch with q integrated on the device.
         Returns the outputs of the last cycle plus ``q`` = joint angles after it."""
         q = np.ascontiguousarray(q, dtype=self.io_dtype)
@@ -307,6 +338,7 @@ class Engine:
         io = IO()
         io.q = q.ctypes.data
         keep = [q]
+        self._host_inputs(io, keep, active, q_lo, q_hi)
         if q_ref is not None:
             a = np.ascontiguousarray(q_ref, dtype=self.io_dtype)
             if a.shape != (self.batch, self.n):
@@ -329,13 +361,16 @@ class Engine:
         """Asynchronous device-pointer form of :meth:`rollout_host`."""
         self._chk(self.lib.vfik_rollout(self.h, C.byref(io), int(n_cycles), float(dt), 1 if clamp else 0, C.c_void_p(_ptr(q_out))))
 
-    def make_io(self, q, null_control=None, q_ref=None, q_cmded=None, **outs):
-        """IO block from device pointers (torch tensors on this device, or raw addresses)."""
+    def make_io(self, q, null_control=None, q_ref=None, q_cmded=None, active=None, q_lo=None, q_hi=None, **outs):
+        """IO block from device pointers (torch tensors on this device, or raw addresses).  active: int32 [B]."""
         io = IO()
         io.q = _ptr(q)
         io.null_control = _ptr(null_control)
         io.q_ref = _ptr(q_ref)
         io.q_cmded = _ptr(q_cmded)
+        io.active = _ptr(active)
+        io.q_lo = _ptr(q_lo)
+        io.q_hi = _ptr(q_hi)
         for k, v in outs.items():
             setattr(io, k, _ptr(v))
         return io
@@ -401,9 +436,11 @@ class Engine:
         self._chk(self.lib.vfik_object_distances(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(frames_dev)), int(max_objects),
                                                  C.c_void_p(_ptr(out_dev))))
 
-    def track_error(self, pose_dev, v6_dev, out_dev):
-        """One step of the tracking-error estimator (vf:349-428) on device arrays."""
-        self._chk(self.lib.vfik_track_error(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(v6_dev)), C.c_void_p(_ptr(out_dev))))
+    def track_error(self, pose_dev, v6_dev, out_dev, active_dev=None):
+        """One step of the tracking-error estimator (vf:349-428) on device arrays; active_dev: int32 [B] gate
+        (arms with 0 append no frame, vf:312-313), or None."""
+        self._chk(self.lib.vfik_track_error(self.h, C.c_void_p(_ptr(pose_dev)), C.c_void_p(_ptr(v6_dev)), C.c_void_p(_ptr(out_dev)),
+                                            C.c_void_p(_ptr(active_dev))))
 
     def track_reset(self):
         self._chk(self.lib.vfik_track_reset(self.h))

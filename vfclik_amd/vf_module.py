@@ -12,7 +12,9 @@ ports under each arm's base name (``<namespace><robotarm_portbasename>``, e.g. `
 
 :meth:`cycle` does what one iteration of each of those loops does -- poll every input non-blocking,
 ignore malformed bottles with a warning, keep sticky state -- and then runs ONE ``vfik_step`` for
-the whole batch.  Arms that received no joint angles this cycle publish nothing (vf:312-313).
+the whole batch.  Arms that received no joint angles this cycle publish nothing AND keep their state
+(vf:312-313, nullspace:162-163): the launch carries a fresh-q gate (``io.active``), so a silent arm's
+nullspace sign memory and its tracking-error history (vf:350-356) do not advance.
 
 Port I/O is per arm and in Python, so this layer is for drop-in use and tests; a caller that already
 holds batched arrays uses :meth:`step_arrays` (or ``Engine`` directly) and never touches a bottle.
@@ -89,7 +91,15 @@ class TrackingState:
 
 class ControlCycleBatch:
     def __init__(self, chain, arm_bases, io_dtype=np.float64, max_fields=16, device=0, nullspace=True,
-                 mixer=True, guard_time=2.0, params=None, open_ports=True, clock=time.time):
+                 mixer=True, guard_time=2.0, params=None, open_ports=True, clock=time.time, initial_joint_pos=None,
+                 limits_fn=None):
+        """initial_joint_pos: `config.initial_joint_pos` -- with it the joint P controller runs for every arm from
+        the first cycle, commanding kp * (initial_joint_pos - q) until a /jpctrl/ref arrives, as the reference's
+        does (joint_p_controller:101); without it an arm has a controller once it got a reference, and until then
+        its mixer channel 2 is whatever arrives on /bridge/jointcmd.
+        limits_fn: `config.updateJntLimits` / `rob.get_limits()` for robots whose limits depend on the pose
+        (joint_p_controller:80,121-125; nullspace:167): called every cycle with q (B, n), returns (lo, hi), each
+        (B, n); None = the chain's static limits."""
         self.chain = chain
         self.bases = list(arm_bases)
         self.B = len(self.bases)
@@ -115,7 +125,12 @@ class ControlCycleBatch:
         self._mon_bufs = None
         self._probe_bufs = None
         self.q_ref = np.zeros((self.B, self.n))          # /jpctrl/ref (joint_p_controller:113-118)
-        self.has_ref = np.zeros(self.B, dtype=bool)      # no reference yet: the controller commands nothing
+        self.has_ref = np.zeros(self.B, dtype=bool)      # arms whose joint controller has a reference
+        if initial_joint_pos is not None:                 # joint_p_controller:101: ref = config.initial_joint_pos
+            self.q_ref[:] = np.asarray(initial_joint_pos, dtype=float).reshape(1, self.n)
+            self.has_ref[:] = True
+        self.limits_fn = limits_fn
+        self._outs = None                                 # output arrays, reused so that gated arms keep their rows
         self.report_counter = 0  # vf:185,432-435
         self.tracking = [TrackingState() for _ in range(self.B)]
         self._track_bufs = None
@@ -277,12 +292,24 @@ class ControlCycleBatch:
         if not got_q.any():
             self.probe()
             return got_q
-        # the joint P controller feeds /bridge/jointcmd (joint_p_controller:78): once any arm has a
-        # reference the fused controller owns mixer channel 2; arms without one get ref = q (zero command)
-        ref = np.where(self.has_ref[:, None], self.q_ref, self.q) if self.has_ref.any() else None
-        out = self.engine.step_host(self.q, null_control=self.control, q_ref=ref,
-                                    want=("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist"))
-        out["track_error"] = self._track_error(out)
+        # the joint P controller feeds /bridge/jointcmd (joint_p_controller:78): for arms with a reference the fused
+        # controller IS mixer channel 2; a NaN row tells the kernel that the arm has none, and its channel 2 stays
+        # the external command that arrived on /bridge/jointcmd
+        ref = None
+        if self.has_ref.any():
+            ref = np.where(self.has_ref[:, None], self.q_ref, np.nan)
+        lo = hi = None
+        if self.limits_fn is not None:  # limits of THIS cycle (nullspace:167, joint_p_controller:80)
+            lo, hi = self.limits_fn(self.q)
+        want = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist") + (("q_ref_out",) if ref is not None else ())
+        # only the arms whose q arrived run their cycle: the others keep their state and publish nothing
+        out = self.engine.step_host(self.q, null_control=self.control, q_ref=ref, want=want, active=got_q, q_lo=lo, q_hi=hi,
+                                    into=self._outs)
+        self._outs = dict(out)
+        if ref is not None:  # the controller keeps the CLAMPED reference (joint_p_controller:121)
+            upd = got_q & self.has_ref
+            self.q_ref[upd] = out["q_ref_out"][upd]
+        out["track_error"] = self._track_error(out, got_q)
         dists = out["object_dist"] = self._object_distances(out)
         self.last = out
         self.report_counter += 1
@@ -327,16 +354,20 @@ class ControlCycleBatch:
         self.probe()
         return got_q
 
-    def _track_error(self, out):
-        """The tracking-error estimator (vf:349-428) for the batch, on the device."""
+    def _track_error(self, out, got_q):
+        """The tracking-error estimator (vf:349-428) for the batch, on the device; it sits inside vf's
+        `if qInBottle` block, so only the arms of got_q append a frame."""
         e = self.engine
         esz = e.io_dtype.itemsize
         if self._track_bufs is None:
-            self._track_bufs = (e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * 6 * esz), e.dev_alloc(self.B * 8 * esz))
-        d_pose, d_v6, d_out = self._track_bufs
+            self._track_bufs = (e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * 6 * esz), e.dev_alloc(self.B * 8 * esz),
+                                e.dev_alloc(self.B * 4))
+            e.h2d(self._track_bufs[2], np.zeros((self.B, 8), dtype=e.io_dtype))
+        d_pose, d_v6, d_out, d_act = self._track_bufs
         e.h2d(d_pose, out["pose"])
         e.h2d(d_v6, out["v6"])
-        e.track_error(d_pose, d_v6, d_out)
+        e.h2d(d_act, np.ascontiguousarray(got_q, dtype=np.int32))
+        e.track_error(d_pose, d_v6, d_out, d_act)
         res = np.zeros((self.B, 8), dtype=e.io_dtype)
         e.d2h(res, d_out)
         return res.astype(np.float64)
@@ -395,7 +426,8 @@ class ControlCycleBatch:
         e.d2h(res, d_out)
         return res.astype(np.float64)
 
-    def step_arrays(self, q, null_control=None, want=("qdot_out",)):
-        """Array path: one cycle for the whole batch without any bottle."""
+    def step_arrays(self, q, null_control=None, want=("qdot_out",), active=None, q_lo=None, q_hi=None):
+        """Array path: one cycle for the whole batch without any bottle -- the way to drive thousands of arms
+        (the per-arm port polling of :meth:`cycle` is a Python loop, meant for drop-in use and tests)."""
         self._push_state()
-        return self.engine.step_host(q, null_control=null_control, want=want)
+        return self.engine.step_host(q, null_control=null_control, want=want, active=active, q_lo=q_lo, q_hi=q_hi)
