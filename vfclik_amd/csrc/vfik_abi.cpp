@@ -64,8 +64,7 @@ struct vfik_handle {
     double tool_shared[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     int tool_per_arm = 0;
     void* d_ext = nullptr;     // [4][B][n], allocated on first use
-    double* d_lastvec = nullptr;  // [n][B]
-    int* d_sig = nullptr;      // [B]
+    float* d_lastvec = nullptr;  // nullspace sign memory, [(n + 4) / 4][Bpad][4] floats (vfik_kernel.h)
     double* d_mixw = nullptr;  // [16]
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     void* d_rollq[2] = {nullptr, nullptr};  // q ping-pong of the stepped rollout (long chains)
@@ -195,7 +194,6 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q_ref = io->q_ref;
     a.q_cmded = io->q_cmded;
     a.lastvec = h->d_lastvec;
-    a.sig = h->d_sig;
     a.qdot_vf = io->qdot_vf;
     a.qdot_null = io->qdot_null;
     a.qdot_out = io->qdot_out;
@@ -297,8 +295,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
     if (dev_alloc(h, &h->d_goal, 4 * quad_plane, true)) return bail("alloc goal");
     if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane, true)) return bail("alloc slots");  // >= 1 slot: the prefetch reads slot 0
-    if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)n_joints * B * sizeof(double), true)) return bail("alloc lastvec");
-    if (dev_alloc(h, (void**)&h->d_sig, B * sizeof(int), false)) return bail("alloc sig");
+    if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float), true)) return bail("alloc lastvec");
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
     if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints) + 2048, true)) return bail("alloc kconst");  // + slack: the kinematics block is copied in whole 1-KiB rows
     h->slots_per_arm.assign(B, 0);
@@ -328,7 +325,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_sig, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     for (auto& ps : h->pipe) {
@@ -636,9 +633,11 @@ int vfik_reset_state(vfik_handle* h) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<int> ones(h->B, 1);
-    HIP_TRY(hipMemsetAsync(h->d_lastvec, 0, (size_t)h->n * h->B * sizeof(double), h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_sig, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    // lastvec = 0, sig = +1 (element n of every arm's state)
+    const size_t planes = (size_t)(h->n + 4) / 4, Bp = h->Bpad;
+    std::vector<float> img(planes * Bp * 4, 0.0f);
+    for (size_t b = 0; b < Bp; ++b) img[((size_t)(h->n / 4) * Bp + b) * 4 + (h->n & 3)] = 1.0f;
+    HIP_TRY(hipMemcpyAsync(h->d_lastvec, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VFIK_OK;
 }

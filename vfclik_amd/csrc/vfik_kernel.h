@@ -25,7 +25,8 @@ namespace vfik {
 //                                     type 0 = empty
 //   tool (per-arm only)   3 planes    frame rows 0,1,2 (a shared tool lives in KConst)
 //   mixw (per-arm only)   2 planes    mixer weights w0..w3 | w4 w5 - -  (shared weights live in KConst)
-//   lastvec               [n][B] double, sig [B] int   (nullspace:91-92 for the unique basis vector)
+//   lastvec               [(n + 4) / 4][Bpad] quads of FLOAT: the unique basis vector of the last cycle (n values), then
+//                                     sig as +-1 / +-2 (nullspace:91-92; vfik_kernel.hip); chains of up to 7 joints only
 //   ext                   [4][B][n]   last commands of mixer channels 2..5
 // Batch-shared constants: chain geometry, limits and parameters.  They live in DEVICE memory (one
 // copy per handle, rewritten only by vfik_set_chain / vfik_set_params) and are read through the
@@ -87,8 +88,7 @@ struct KArgs {
     const double* wts;    // per-arm IK weights [6 + n][Bpad] (wy rows, then wq rows), or NULL (KConst::wy / wq)
     const void* q_ref;    // [B][n] joint P controller reference (mixer channel 2), or NULL
     const void* q_cmded;  // [B][n] LWR echo of the commanded position (bridge:199-203 command form), or NULL
-    double* lastvec;
-    int* sig;
+    float* lastvec;
     void* qdot_vf;
     void* qdot_null;
     void* qdot_out;

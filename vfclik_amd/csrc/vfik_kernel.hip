@@ -69,6 +69,11 @@ __device__ __forceinline__ double mac_unfused(double acc, double x, double w) {
     return acc + prod;
 }
 
+__device__ __forceinline__ double mul_unfused(double x, double w) {
+#pragma clang fp contract(off)
+    return x * w;
+}
+
 // sin and cos: Cody-Waite reduction by pi/2 in three parts, then the classic minimax kernels on
 // [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos), < 1 ulp for |x| up to ~1e5 rad.
 // Joint angles live inside their limits (a few radians).
@@ -472,11 +477,15 @@ template <typename T> struct SlotLds {
 // not in the kernel at all -- present but never executed, it cost the C3 launch 4.5 % (6.47 -> 6.18 us, same box).
 // amdgpu_waves_per_eu(1, 1): one wave per SIMD is what the launch gets anyway (registers, LDS); telling the backend
 // lets its scheduler stop trading instruction order for a register count it cannot use (C3 -2.4 %, same-box A/B).
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN>
+// CF = the feature flags as a compile-time constant, or -1: read from the launch.  The two flag sets the reference's
+// default process set produces with the nullspace module (vfclik:95-97: nullspace + mixer; C5 adds the joint-limit
+// task) get their own LEAN kernels, so that the branches of the other options are not in the code at all.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) cycle_kernel(const KArgs a_in) {
     KArgs a = a_in;
+    if constexpr (CF >= 0) a.flags = (unsigned)CF;
     if constexpr (LEAN != 0) {  // 1: lean, 2: lean with q_out kept (one cycle of a stepped rollout, long chains)
-        if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags stay run-time: joint-limit task, mixer, limiter)
+        if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags are run-time unless CF fixes them)
         a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
         a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
         a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr;
@@ -582,14 +591,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
+    bool has_vec = false;  // lastvec holds a vector (false until the first cycle with a unique nullspace direction)
     double lv_r[NJ];
-    if constexpr (NULLSP && NJ <= 7) {  // requested here, a kinematics phase ahead of its use: read where it is used,
-        // the round trip stood in the wave's way (~1 500 cycles).  Chains of 8+ joints have nullity >= 2 and
-        // never use the sign memory.
-        sig_r = a.sig[arm];
+    // Nullspace state of an arm (nullspace:91-92), chains of up to 7 joints: lastvec (n values) and sig, kept as
+    // FLOATs in (n + 4) / 4 planes of 16 bytes per arm -- element n holds sig as +-1 (no vector stored yet) or +-2
+    // (lastvec holds one).  The state only steers decisions (the sign continuity test) and seeds the projection
+    // below; the vector that is published is recomputed in float64 every cycle.  As doubles the state was 4.2 MB
+    // written per C3 launch: 0.3 us of the launch period (measured by leaving the store out).
+    constexpr int NS_PLANES = (NJ + 4) / 4;
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    auto store_null_state = [&]() {
+        f4s* sp = reinterpret_cast<f4s*>(a.lastvec) + arm;
+        float sv[NS_PLANES * 4];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) lv_r[i] = a.lastvec[i * Bs + arm];
-    }
+        for (int i = 0; i < NS_PLANES * 4; ++i) sv[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) sv[i] = (float)lv_r[i];
+        sv[NJ] = (float)sig_r * (has_vec ? 2.0f : 1.0f);
+#pragma unroll
+        for (int k = 0; k < NS_PLANES; ++k) {
+            f4s v;
+            v.x = sv[4 * k]; v.y = sv[4 * k + 1]; v.z = sv[4 * k + 2]; v.w = sv[4 * k + 3];
+            sp[(long)k * a.Bpad] = v;
+        }
+    };
+    // The state is requested a phase ahead of its use (read where it is used, the round trip stood in the wave's
+    // way, ~1 500 cycles): a rollout loads it here, once; a single cycle requests it in front of the Gram-Schmidt
+    // block, which covers the latency without the registers being held through kinematics, field and IK.
+    // Chains of 8+ joints have nullity >= 2 and never use the sign memory.
+    auto load_null_state = [&]() {
+        const f4s* sp = reinterpret_cast<const f4s*>(a.lastvec) + arm;
+        float sv[NS_PLANES * 4];
+#pragma unroll
+        for (int k = 0; k < NS_PLANES; ++k) {
+            const f4s v = sp[(long)k * a.Bpad];
+            sv[4 * k] = v.x; sv[4 * k + 1] = v.y; sv[4 * k + 2] = v.z; sv[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) lv_r[i] = (double)sv[i];
+        sig_r = sv[NJ] < 0.0f ? -1 : 1;
+        has_vec = fabsf(sv[NJ]) > 1.5f;
+    };
+    if constexpr (NULLSP && NJ <= 7 && ROLL) load_null_state();
     const int ncyc = ROLL ? a.n_cycles : 1;
     for (int cyc = 0; cyc < ncyc; ++cyc) {
     // The LDS addresses are made opaque once per cycle for long chains: otherwise the compiler hoists the
@@ -1165,101 +1208,150 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int i = 0; i < NJ; ++i)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
+            if constexpr (!ROLL) load_null_state();
             // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
             // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
             // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
+            // Right-looking order: once row s is normalised, the projections of ALL later rows onto it are
+            // independent chains (5, 4, ... of them) that a lone wave can interleave; row by row (left-looking) the
+            // same operations are one serial chain of 7-term dot products (dependent float64 ops issue every ~8
+            // cycles, independent ones every ~5).  Same arithmetic, same order per row: same results.
             int rank = 0;
+            double n0[6];  // squared norms of the rows of J: the rank test's yardstick
     #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double n0 = 0.0;
+            for (int r = 0; r < 6; ++r) n0[r] = Jm[0][r] * Jm[0][r];
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) n0 += Jm[i][r] * Jm[i][r];
+            for (int i = 1; i < NJ; ++i)
     #pragma unroll
-                for (int s = 0; s < r; ++s) {
-                    double c = 0.0;
+                for (int r = 0; r < 6; ++r) n0[r] = __builtin_fma(Jm[i][r], Jm[i][r], n0[r]);
     #pragma unroll
-                    for (int i = 0; i < NJ; ++i) c += Jm[i][s] * Jm[i][r];
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) Jm[i][r] -= c * Jm[i][s];
-                }
+            for (int s = 0; s < 6; ++s) {
                 double n1 = 0.0;
+                if (s == 0) {
+                    n1 = n0[0];  // nothing has been projected out of the first row
+                } else {
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) n1 += Jm[i][r] * Jm[i][r];
-                const bool keep = n1 > 1e-24 * n0 && n0 > 0.0;
+                    for (int i = 0; i < NJ; ++i) n1 += Jm[i][s] * Jm[i][s];
+                }
+                const bool keep = n1 > 1e-24 * n0[s] && n0[s] > 0.0;
                 double n1r, n1i;
                 sqrt_rsqrt(n1, n1r, n1i);
                 const double inv = keep ? n1i : 0.0;
                 rank += keep ? 1 : 0;
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) Jm[i][r] *= inv;
+                for (int i = 0; i < NJ; ++i) Jm[i][s] *= inv;
+                double c[6];
+    #pragma unroll
+                for (int r = s + 1; r < 6; ++r) c[r] = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i)
+    #pragma unroll
+                    for (int r = s + 1; r < 6; ++r) c[r] += Jm[i][s] * Jm[i][r];
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i)
+    #pragma unroll
+                    for (int r = s + 1; r < 6; ++r) Jm[i][r] -= c[r] * Jm[i][s];
             }
             const int nullity = NJ - rank;
             if (nullity == 1) {
                 // the unique nullspace direction: normalised column of the projector with the largest diagonal
                 double best = -1.0;
                 int ib = 0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    double d = 1.0;
-    #pragma unroll
-                    for (int r = 0; r < 6; ++r) d -= Jm[i][r] * Jm[i][r];
-                    if (d > best) { best = d; ib = i; }
-                }
                 double u[NJ];
+                // u <- (I - Q^T Q) u: all six coefficients first (independent dot products), then the update (classical
+                // Gram-Schmidt against an orthonormal Q); returns the largest |coefficient| = how much of u was row space
+                auto project = [&]() {
+                    double c[6];
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) u[i] = (i == ib) ? 1.0 : 0.0;
+                    for (int r = 0; r < 6; ++r) c[r] = 0.0;
     #pragma unroll
-                for (int pass = 0; pass < 2; ++pass)
+                    for (int i = 0; i < NJ; ++i)
     #pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        double c = 0.0;
+                        for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * u[i];
     #pragma unroll
-                        for (int i = 0; i < NJ; ++i) c += Jm[i][r] * u[i];
+                    for (int r = 0; r < 6; ++r)
     #pragma unroll
-                        for (int i = 0; i < NJ; ++i) u[i] -= c * Jm[i][r];
-                    }
+                        for (int i = 0; i < NJ; ++i) u[i] -= c[r] * Jm[i][r];
+                    double cm = fabs(c[0]);
+    #pragma unroll
+                    for (int r = 1; r < 6; ++r) cm = fmax(cm, fabs(c[r]));
+                    return cm;
+                };
                 double nn = 0.0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
+                // Warm start: the nullspace direction turns little between two control cycles, so last cycle's vector
+                // (the sign memory, nullspace:92,104) is projected instead of a unit vector: no search for the best
+                // unit vector, and ONE projection suffices when it removes little (its residual row-space part is
+                // ~ eps cond(J) times what was removed).  Any lane without a usable previous vector (first cycle, a
+                // jump) sends its wave down the cold path below.
+                bool warm = false;
                 {
-                    double nr_, ni_;
-                    sqrt_rsqrt(nn, nr_, ni_);
-                    nn = ni_;
-                }
-                // raw sign as LAPACK's SVD leaves it (first non-negligible component negative; oracle + golden)
-                bool found = false;
-                double sg = 1.0;
+                    if (__all(has_vec)) {  // (a stored vector is a unit vector)
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    u[i] *= nn;
-                    if (!found && fabs(u[i]) > 1e-9) { found = true; sg = u[i] > 0.0 ? -1.0 : 1.0; }
+                        for (int i = 0; i < NJ; ++i) u[i] = lv_r[i];
+                        const double cm = project();
+    #pragma unroll
+                        for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
+                        if (__all(nn > 0.25)) {
+                            warm = true;
+                            if (__any(cm > 1e-2)) {  // a real move: project once more, as the cold path does
+                                project();
+                                nn = 0.0;
+    #pragma unroll
+                                for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
+                            }
+                        }
+                    }
                 }
-                // sign continuity against the previous cycle (nullspace:101-105)
+                if (!warm) {
+                    double dg[NJ];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) dg[i] = 1.0;
+    #pragma unroll
+                    for (int r = 0; r < 6; ++r)
+    #pragma unroll
+                        for (int i = 0; i < NJ; ++i) dg[i] -= Jm[i][r] * Jm[i][r];
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i)
+                        if (dg[i] > best) { best = dg[i]; ib = i; }
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) u[i] = (i == ib) ? 1.0 : 0.0;
+                    project();  // twice: the second pass squares the residual
+                    project();
+                    nn = 0.0;
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
+                }
+                double nrm, ninv;
+                sqrt_rsqrt(nn, nrm, ninv);
+                // All three sign decisions are taken on the un-normalised u and applied with the normalisation, in one
+                // multiplication per joint.  (1) The raw vector v as LAPACK's SVD leaves it: the first component that is
+                // not negligible (|v_i| > 1e-9 of the unit vector) is negative (oracle + golden).
+                const double thr = 1e-9 * nrm;
+                bool found = false, negate = false;  // negate: v = -u / |u|
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i)
+                    if (!found && fabs(u[i]) > thr) { found = true; negate = u[i] > 0.0; }
+                // (2) sign continuity against the previous cycle (nullspace:101-105): sig flips when sig v is farther from
+                // lastvec than -sig v; |sig v - l|^2 - |sig v + l|^2 = -4 sig (v . l), so only the sign of v . l counts
+                double dot = 0.0;
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) dot += u[i] * lv_r[i];
                 int sig = sig_r;
-                double dm = 0.0, dp = 0.0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    u[i] *= sg;
-                    const double lv = lv_r[i];
-                    const double x = sig * u[i] - lv, y = sig * u[i] + lv;
-                    dm += x * x; dp += y * y;
-                }
-                if (sqrt(dm) > sqrt(dp)) sig = -sig;
+                const double vl = negate ? -dot : dot;
+                if ((sig < 0 ? -vl : vl) < 0.0) sig = -sig;
                 sig_r = sig;
+                has_vec = true;
+                const double k = (negate != (sig < 0)) ? -ninv : ninv;
                 double c0 = 0.0;
                 if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
     #pragma unroll
                 for (int i = 0; i < NJ; ++i) {
-                    u[i] *= sig;
+                    u[i] *= k;
                     lv_r[i] = u[i];
                     qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
                 }
                 if constexpr (!ROLL) {
-                    if (act) {
-                        a.sig[arm] = sig_r;
-    #pragma unroll
-                        for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
-                    }
+                    if (act) store_null_state();
                 }
             } else if (nullity >= 2) {
                 status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
@@ -1267,14 +1359,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
                 double z[NJ];
                 jl_descent(z);
+                double c[6];
     #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    double c = 0.0;
+                for (int r = 0; r < 6; ++r) c[r] = 0.0;
     #pragma unroll
-                    for (int i = 0; i < NJ; ++i) c += Jm[i][r] * z[i];
+                for (int i = 0; i < NJ; ++i)
     #pragma unroll
-                    for (int i = 0; i < NJ; ++i) z[i] -= c * Jm[i][r];
-                }
+                    for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * z[i];
+    #pragma unroll
+                for (int r = 0; r < 6; ++r)
+    #pragma unroll
+                    for (int i = 0; i < NJ; ++i) z[i] -= c[r] * Jm[i][r];
     #pragma unroll
                 for (int i = 0; i < NJ; ++i) qn[i] += z[i];
             }
@@ -1320,7 +1415,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     if (a.flags & VFIK_F_MIXER) {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mac_unfused(0.0, qv[i], mw[0]), qn[i], mw[1]);
+        for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mul_unfused(qv[i], mw[0]), qn[i], mw[1]);  // (0.0 + x w is x w up to the sign of zero)
         if (a.q_ref) {  // joint P controller -> /bridge/jointcmd = channel 2 (joint_p_controller:78,89-99,124-128)
             const T* rf = static_cast<const T*>(a.q_ref) + (long)arm * NJ;
             double rlo[NJ], rhi[NJ];
@@ -1455,11 +1550,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     }  // cycles of this launch
     if (!act) return;  // (no store has been made for this arm)
-    if constexpr (NULLSP && ROLL && NJ <= 7) {
-        a.sig[arm] = sig_r;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) a.lastvec[i * Bs + arm] = lv_r[i];
-    }
+    if constexpr (NULLSP && ROLL && NJ <= 7) store_null_state();
     if (a.q_out) {
         T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
 #pragma unroll
@@ -1658,6 +1749,19 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     }
     if constexpr (PL) {
         if (lean && !a.q_out) {
+            // (chains of up to 7 joints: C3N -1 %; the 14-joint kernel got 10 % SLOWER with its flags fixed -- the
+            // compiler then hoists the joint-limit task's constants over the whole kernel -- and keeps them run-time)
+            if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
+                constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
+                if (a.flags == (unsigned)NSMIX) {
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds, stream, a);
+                    return;
+                }
+                if (a.flags == (unsigned)NSJLMIX) {
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds, stream, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds, stream, a);
             return;
         }
