@@ -169,6 +169,7 @@ def parse_args(argv=None):
                     help="nccl (= RCCL) is the real thing; gloo + --single-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
+    ap.add_argument("--dump-reps", default=None, help="diagnostic: write the per-repetition times (us per launch, HIP events) to this file")
     ap.add_argument("--sync-each", action="store_true",
                     help="diagnostic: synchronize after every launch (un-overlapped kernel durations for a rocprofv3 kernel trace); "
                          "the line is then not a throughput measurement")
@@ -350,6 +351,9 @@ def worker(args):
         med_s, p10_s, p90_s = pctl(wall_s, 50), pctl(wall_s, 10), pctl(wall_s, 90)
         us_launch = [m * 1e3 / K for m in ev_ms]
         us_med = pctl(us_launch, 50)
+        if args.dump_reps:
+            with open(args.dump_reps, "w") as f:
+                f.write("\n".join("%.4f %.4f" % (u, ws * 1e6 / K) for u, ws in zip(us_launch, wall_s)) + "\n")
         achieved = bytes_per_cycle * B / (us_med * 1e-6) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Same-box A/B of two builds of libvfik_hip.so: alternating bench.py runs, HIP-event time per launch.
+"""Same-box A/B of two builds of libvfik_hip.so: alternating bench.py runs; per run the p10 over 30 repetitions of the
+HIP-event time per launch (200 launches each), then median and best over the rounds (a box's clock wanders by several %).
 
 Between gpurun boxes the same binary varies by +-1.5 %, so only runs on one box compare.  Build the variant out of
 tree (copy vfclik_amd/csrc + include to /tmp, patch, `make`), drop its .so under tools/ and run on the GPU box:
@@ -25,7 +26,7 @@ def run(lib, workload):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--no-cpu-baseline", "--host-path", "0",
                           "--rollout", "0", "--steps", "200", "--reps", "30"], env=env, capture_output=True, text=True, timeout=300)
     d = json.loads(out.stdout.strip().split("\n")[-1])
-    return d["roofline"]["us_per_launch_hip_events"], d["max_abs_err_rad_s"]
+    return d["roofline"]["us_per_launch_p10"], d["max_abs_err_rad_s"]
 
 
 def main():
@@ -45,7 +46,7 @@ def main():
     base = sorted(res["in-tree"])[len(res["in-tree"]) // 2]
     for n in names:
         med = sorted(res[n])[len(res[n]) // 2]
-        print("%-40s %s  median %.3f us (%+.1f %%)  max err %.3g" % (n, " ".join("%.3f" % x for x in res[n]), med, 100 * (med / base - 1), err[n]))
+        print("%-40s %s  median %.3f us (%+.1f %%)  best %.3f (%+.1f %%)  max err %.3g" % (n, " ".join("%.3f" % x for x in res[n]), med, 100 * (med / base - 1), min(res[n]), 100 * (min(res[n]) / min(res["in-tree"]) - 1), err[n]))
 
 
 if __name__ == "__main__":

@@ -63,6 +63,9 @@ struct KConst {
     static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
     static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
+// The device image of the constants is KConst<NJ> padded to a multiple of 1 KiB, then the 1-KiB sin / cos table
+// ((sin, cos)(k pi/32), k = 0..63) that every wave copies to LDS with the kinematics block.
+template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KConst<NJ>) + 1023) / 1024 * 1024; };
 
 // Chains longer than this have no registers left for loop-carried state: their rollout is a sequence of
 // single-cycle launches that integrate q on the way out (vfik_abi.cpp), not the ROLL kernel variant.

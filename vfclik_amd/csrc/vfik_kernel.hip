@@ -40,6 +40,15 @@ __device__ __forceinline__ double rcp_nr(double x) {  // 1/x, ~1 ulp, x normal a
     return __builtin_fma(y, e, y);
 }
 
+// 1/sqrt(x) from ONE Newton step on v_rsq_f64 (5 instructions, relative error ~1e-14): enough for the decay repellers,
+// whose magnitude ((radius + safe) / D)^order feeds a vector that is normalised afterwards; sqrt_rsqrt's two
+// Goldschmidt steps (10 instructions, ~1 ulp) stay where the value itself is published.  x = 0 gives a large finite value.
+__device__ __forceinline__ double rsqrt_1nr(double x) {
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+
 // sqrt(x) and 1/sqrt(x) together (Goldschmidt from v_rsq_f64).  x = 0 gives (0, large finite).
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& root, double& inv) {
     const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
@@ -154,6 +163,51 @@ __device__ __forceinline__ void sincos_fast_n(const double* x, double* s, double
         s[i] = (n & 2) ? -sv : sv;
         c[i] = ((n + 1) & 2) ? -cv : cv;
     }
+}
+
+// sin and cos of N independent arguments through a 64-entry table: x = k pi/32 + r, |r| <= pi/64, and
+//   sin x = S_k cos r + C_k sin r,   cos x = C_k cos r - S_k sin r
+// with (S_k, C_k) = (sin, cos)(k pi/32) read from the wave's LDS copy of the table (one 16-byte read per angle, index
+// k mod 64) and Taylor polynomials that are exact to the last bit on so short an interval (r^9/9! < 1e-16 r,
+// r^10/10! < 3e-20).  23 instructions an angle against 33 for the pi/2 reduction above, whose minimax kernels need
+// six coefficients each and a sign / swap selection by quadrant; ~2 ulp (the table entries are rounded).  pi/32 is
+// split into a 33-bit head, so that k * head is exact for |x| < 1e5 rad, and a tail.
+template <int N>
+__device__ __forceinline__ void sincos_tab_n(const double* x, const char* tab, double* s, double* c) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double k[N], r[N], z[N], ps[N], pc[N], S[N], C[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = __builtin_rint(x[i] * 10.185916357881302);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const d2 t = *reinterpret_cast<const d2*>(tab + (((int)k[i]) & 63) * 16);
+        S[i] = t.x; C[i] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-k[i], 0.09817477042088285, x[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-k[i], 3.79818781656637e-12, r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], -1.98412698412698412698e-04, 8.33333333333333333333e-03);
+        pc[i] = __builtin_fma(z[i], 2.48015873015873015873e-05, -1.38888888888888888889e-03);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = __builtin_fma(z[i], ps[i], -1.66666666666666666667e-01);
+        pc[i] = __builtin_fma(z[i], pc[i], 4.16666666666666666667e-02);
+    }
+    double zr[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { zr[i] = z[i] * r[i]; pc[i] = __builtin_fma(z[i], pc[i], -0.5); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { ps[i] = __builtin_fma(zr[i], ps[i], r[i]); pc[i] = __builtin_fma(z[i], pc[i], 1.0); }  // sin r, cos r
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s[i] = S[i] * pc[i]; c[i] = C[i] * pc[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s[i] = __builtin_fma(C[i], ps[i], s[i]); c[i] = __builtin_fma(-S[i], ps[i], c[i]); }
 }
 
 // N independent 1/sqrt(x), operation by operation (x = 0 gives a large finite value)
@@ -387,7 +441,8 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
     __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4) * 8 + 1023) / 1024; }
     __host__ __device__ static constexpr int kin_off(int nj) { return QROWS * 1024 + qregion(nj); }
-    __host__ __device__ static constexpr int bytes(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }
+    __host__ __device__ static constexpr int tab_off(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }  // sin / cos table, 1 KiB
+    __host__ __device__ static constexpr int bytes(int nj) { return tab_off(nj) + 1024; }
 };
 
 // LDS byte address (relative to the q area) of byte b of this lane's q vector
@@ -499,6 +554,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                  "s"(a.tool), "s"(a.mixw), "s"(a.kc));
     const int arm = blockIdx.x * a.block + threadIdx.x;
     const long Bs = a.B;
+    constexpr bool TABSC = NJ <= 8;  // sin / cos through the LDS table (sincos_tab_n)
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
     const KcPtr kc_launch = (KcPtr)(unsigned long long)a.kc;
@@ -520,6 +576,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int r = 0; r < KConst<NJ>::KIN_ROWS; ++r)
             __builtin_amdgcn_global_load_lds((GPtr)(kg + r * 1024), (LPtr)(region + Stage<T>::kin_off(NJ) + r * 1024), 16, 0, 0);
+        // the sin / cos table (64 x 16 bytes) sits behind the constants, on the next 1-KiB boundary
+        if constexpr (TABSC) __builtin_amdgcn_global_load_lds((GPtr)(kg + KTab<NJ>::OFFSET), (LPtr)(region + Stage<T>::tab_off(NJ)), 16, 0, 0);
     }
     if (arm >= a.B) return;
     // Fresh-q gate (vf:312-313, nullspace:162-163): an arm whose joint angles did not arrive this cycle stores
@@ -573,7 +631,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
-    VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, tool and q have landed (the goal and early slot requests may still be out)
+    VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal and early slot requests may still be out)
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
     STAMP(2);
     {
@@ -689,7 +747,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         double ang[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) ang[i] = q[i] + klc->dh[i].off;
-        sincos_fast_n<NJ>(ang, sn, cs);
+        // Chains of up to 8 joints go through the LDS table (C3 -2 %, C3N -3.5 %, C2 -2.5 % in same-box A/Bs).  Long
+        // chains keep the table-free form: the 14-joint kernel has no registers for 28 table values on top of its
+        // Jacobian and was 2-4 % SLOWER with the table, all angles at once, in two halves or inside the kinematics.
+        if constexpr (TABSC) sincos_tab_n<NJ>(ang, reinterpret_cast<const char*>(klc) + (Stage<T>::tab_off(NJ) - Stage<T>::kin_off(NJ)), sn, cs);
+        else sincos_fast_n<NJ>(ang, sn, cs);
     }
     double R[9], p[3];
 #pragma unroll
@@ -977,9 +1039,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 double di[PRE], rb[PRE], rp[PRE];
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
-                    double D;
-                    sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
-                    di[m] = fmin(di[m], 1.0 / D_FLOOR);
+                    di[m] = fmin(rsqrt_1nr(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m]), 1.0 / D_FLOOR);
                     rb[m] = rs[m] * di[m];
                     rp[m] = 1.0;
                 }
@@ -1058,9 +1118,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     }
 #pragma unroll
                     for (int m = 0; m < PRE; ++m) {
-                        double D;
-                        sqrt_rsqrt(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m], D, di[m]);
-                        di[m] = fmin(di[m], 1.0 / D_FLOOR);
+                        di[m] = fmin(rsqrt_1nr(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m]), 1.0 / D_FLOOR);
                         rb[m] = rsum[m] * di[m];
                         rp[m] = 1.0;
                     }
@@ -1917,6 +1975,13 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     for (int i = 0; i < 6; ++i) pl = pl && p.wy[i] == 1.0;
     for (int i = 0; i < NJ; ++i) pl = pl && p.wq[i] == 1.0;
     *plain = pl ? 1 : 0;
+    // (sin, cos)(k pi/32), k = 0 .. 63, for sincos_tab_n
+    double* tab = reinterpret_cast<double*>(static_cast<char*>(dst) + KTab<NJ>::OFFSET);
+    for (int k = 0; k < 64; ++k) {
+        const long double a = (long double)k * 3.14159265358979323846264338327950288L / 32.0L;
+        tab[2 * k] = (double)sinl(a);
+        tab[2 * k + 1] = (double)cosl(a);
+    }
     return worst;
 }
 
@@ -1939,9 +2004,9 @@ hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hip
     }
 }
 
-size_t kconst_bytes(int nj) {
+size_t kconst_bytes(int nj) {  // the constants, padded to 1 KiB, and the sin / cos table behind them
     switch (nj) {
-#define X(n) case n: return sizeof(KConst<n>);
+#define X(n) case n: return KTab<n>::OFFSET + 1024;
         VFIK_NJ_LIST
 #undef X
         default: return 0;
