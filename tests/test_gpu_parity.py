@@ -568,3 +568,24 @@ def test_lean_selection_honours_external_channels(env):
     ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], ext_cmd=ext)
     assert np.abs(got["qdot_out"] - ref["qdot_out"]).max() < TOL64
     eng.close()
+
+
+@pytest.mark.parametrize("robot,nobs", [("lwr_dual14", 9), ("lwr_dual14", 12), ("lwr_dual14", 13), ("lwr_dual14", 16), ("lwr_dual14", 17),
+                                        ("lwr_dual14", 20), ("lwr_dual14", 24), ("lwr_dual14", 31), ("lwr10", 14), ("lwr", 19)])
+def test_slot_ring_of_long_chains(env, robot, nobs):
+    """Long chains with float I/O keep a ring of 12 resident slots and evaluate 8 at a time (vfik_kernel.hip, Stage::cap):
+    every count around the ring and chunk sizes, ragged per arm, against the oracle."""
+    if robot == "lwr10":  # a 10-joint chain (the library is built for 6, 7, 10, 14): the LWR behind a 3-joint arm
+        from vfclik_amd.chain import Chain
+        front = Chain.from_dh([(0.1, np.pi / 2, 0.2, 0.0), (0.3, 0.0, 0.0, 0.0), (0.0, np.pi / 2, 0.0, 0.0)], [-2.0] * 3, [2.0] * 3, name="front3")
+        chain = front.concat(env.robots.lwr(), name="lwr10")
+    else:
+        chain = env.robots.by_name(robot)
+    B = 200
+    w = env.synth.make_workload(chain, B, nobs, seed=nobs, io_dtype=np.float32)
+    w["nfields"] = (1 + (np.arange(B) * 7) % (nobs + 1)).astype(np.int32)  # 1 .. nobs+1 fields: ragged
+    w["nfields"][:4] = nobs + 1
+    flags = env.abi.F_NULLSPACE | env.abi.F_JOINT_LIMIT_TASK | env.abi.F_MIXER if chain.n >= 8 else 0
+    params = env.abi.default_params(flags=flags)
+    got, ref = _run_both(env, chain, params, w, np.float32, want=("qdot_out", "status"), max_slots=nobs)
+    _compare(got, ref, TOL32, ("qdot_out", "status"))
