@@ -572,9 +572,9 @@ def test_lean_selection_honours_external_channels(env):
 
 @pytest.mark.parametrize("robot,nobs", [("lwr_dual14", 9), ("lwr_dual14", 12), ("lwr_dual14", 13), ("lwr_dual14", 16), ("lwr_dual14", 17),
                                         ("lwr_dual14", 20), ("lwr_dual14", 24), ("lwr_dual14", 31), ("lwr10", 14), ("lwr", 19)])
-def test_slot_ring_of_long_chains(env, robot, nobs):
-    """Long chains with float I/O keep a ring of 12 resident slots and evaluate 8 at a time (vfik_kernel.hip, Stage::cap):
-    every count around the ring and chunk sizes, ragged per arm, against the oracle."""
+def test_slot_counts_around_the_chunk_boundaries(env, robot, nobs):
+    """More slots than one staged chunk (8 with float I/O): counts around every chunk boundary, ragged per arm, on the
+    10- and 14-joint kernels (and 7) against the oracle."""
     if robot == "lwr10":  # a 10-joint chain (the library is built for 6, 7, 10, 14): the LWR behind a 3-joint arm
         from vfclik_amd.chain import Chain
         front = Chain.from_dh([(0.1, np.pi / 2, 0.2, 0.0), (0.3, 0.0, 0.0, 0.0), (0.0, np.pi / 2, 0.0, 0.0)], [-2.0] * 3, [2.0] * 3, name="front3")
