@@ -8,89 +8,71 @@ Run ONLY in the build container (the reference tree does not exist on the GPU bo
 Writes tests/golden/mixer_golden.npz and tests/golden/nullspace_golden.npz.  Only
 arrays (inputs and the reference's outputs) are stored; no reference source travels.
 
-What is executed from the reference:
-  * src/command_mixer.py   -> CommandMixer.__init__/read   (command_mixer.py:32-82)
-  * scripts/nullspace      -> restrict, nullspace, move_in_nullspace, check_limits
-                              (nullspace:75-131), module globals sig/lastvec (:91-92)
+What is executed from the reference -- ONLY these definitions, nothing else of the files:
+  * src/command_mixer.py   -> class CommandMixer (__init__/read, command_mixer.py:32-82)
+  * scripts/nullspace      -> restrict, nullspace, move_in_nullspace, check_limits, matrixrank, sign
+                              (nullspace:67-131) and the module globals sig / lastvec (:91-92)
 
-Both files import modules that do not exist here (yarp, arcospyu.*).  None of the
-functions above calls into them, so this harness registers empty placeholder
-modules under those names for the duration of the import; the reference files are
-not modified.  scripts/nullspace needs numpy<2 (`from numpy import mat`), hence
-python3.9 + numpy 1.26.4.
+The reference tree is untrusted content: the files are read as TEXT, parsed with `ast`, and only the
+whitelisted top-level definitions (plus the files' own `import numpy` / `from numpy ... import` / `import time`
+lines) are compiled and executed in a fresh namespace.  Their module-level side effects (signal handlers,
+prctl process renaming, yarp initialisation, port creation, the control loops) never run, no module of the
+reference is imported, and nothing is written next to it (`sys.dont_write_bytecode`).  scripts/nullspace needs
+numpy<2 (`from numpy import mat`), hence python3.9 + numpy 1.26.4.
 """
-import importlib.machinery
-import importlib.util
+import ast
 import os
 import sys
-import types
 
-import numpy as np
+sys.dont_write_bytecode = True  # never leave __pycache__ inside the read-only reference tree
+
+import numpy as np  # noqa: E402
 
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 # ----------------------------------------------------------------------------
-# placeholder modules so that the module-level imports succeed
+# extraction: whitelisted definitions of a reference file, executed in a fresh namespace
 # ----------------------------------------------------------------------------
-class _Cfg:
-    nJoints = 7
-    robotarm_portbasename = "/lwr/right"
+_ALLOWED_IMPORTS = {"numpy", "numpy.linalg", "numpy.linalg.linalg", "time", "math"}
 
 
-class _Opts:
-    namespace = "/0"
+def _extract(path, names, preset=None):
+    """Namespace holding the top-level functions / classes / assignments called `names` of the file at `path`
+    (read as text), plus the file's own imports of numpy / time / math.  Nothing else of the file is executed."""
+    with open(path, "r") as f:
+        tree = ast.parse(f.read(), filename=path)
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.Import):
+            if all(a.name in _ALLOWED_IMPORTS for a in node.names):
+                keep.append(node)
+        elif isinstance(node, ast.ImportFrom):
+            if node.module in _ALLOWED_IMPORTS and node.level == 0:
+                keep.append(node)
+        elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            if node.name in names:
+                keep.append(node)
+        elif isinstance(node, ast.Assign):
+            if all(isinstance(t, ast.Name) and t.id in names for t in node.targets):
+                keep.append(node)
+    found = {n.name for n in keep if isinstance(n, (ast.FunctionDef, ast.ClassDef))} | \
+            {t.id for n in keep if isinstance(n, ast.Assign) for t in n.targets}
+    missing = set(names) - found
+    if missing:
+        raise RuntimeError("%s: definitions not found: %s" % (path, sorted(missing)))
+    ns = dict(preset or {})
+    ns["__name__"] = "extracted_" + os.path.basename(path)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
 
 
-def _install_placeholders(n_joints):
-    _Cfg.nJoints = n_joints
-    yarp = types.ModuleType("yarp")
+class _NS:
+    """attribute access to an extracted namespace (so that module globals like sig / lastvec stay shared)"""
 
-    class _Net:
-        @staticmethod
-        def init():
-            pass
-
-    yarp.Network = _Net
-    arcospyu = types.ModuleType("arcospyu")
-    cp = types.ModuleType("arcospyu.config_parser")
-
-    class ConfigFileParser:
-        def __init__(self, *a, **k):
-            pass
-
-        def get_all(self):
-            return _Opts(), [], _Cfg()
-
-    cp.ConfigFileParser = ConfigFileParser
-    rt = types.ModuleType("arcospyu.robot_tools")
-
-    class Lafik:
-        def __init__(self, *a, **k):
-            pass
-
-    rt.Lafik = Lafik
-    yt = types.ModuleType("arcospyu.yarp_tools")
-    ych = types.ModuleType("arcospyu.yarp_tools.yarp_comm_helpers")
-
-    class ArcosYarp:
-        def __init__(self, *a, **k):
-            pass
-
-    ych.ArcosYarp = ArcosYarp
-    for name, mod in [("yarp", yarp), ("arcospyu", arcospyu), ("arcospyu.config_parser", cp),
-                      ("arcospyu.robot_tools", rt), ("arcospyu.yarp_tools", yt),
-                      ("arcospyu.yarp_tools.yarp_comm_helpers", ych)]:
-        sys.modules[name] = mod
-
-
-def _load(path, name):
-    loader = importlib.machinery.SourceFileLoader(name, path)
-    spec = importlib.util.spec_from_loader(name, loader)
-    mod = importlib.util.module_from_spec(spec)
-    loader.exec_module(mod)
-    return mod
+    def __init__(self, ns):
+        self.__dict__ = ns
 
 
 # ----------------------------------------------------------------------------
@@ -138,8 +120,7 @@ class _Clock:
 
 
 def make_mixer_golden():
-    _install_placeholders(7)
-    cm = _load(os.path.join(REF, "src", "command_mixer.py"), "ref_command_mixer")
+    cm = _NS(_extract(os.path.join(REF, "src", "command_mixer.py"), ["CommandMixer"]))
     clock = _Clock()
     cm.time = clock  # module attribute used as time.time() (command_mixer.py:44,60,64)
     rng = np.random.default_rng(20261004)
@@ -222,8 +203,10 @@ def _rand_jac(rng, n):
 def make_nullspace_golden():
     out = {}
     for n in (7, 14, 6):
-        _install_placeholders(n)
-        ns = _load(os.path.join(REF, "scripts", "nullspace"), "ref_nullspace_%d" % n)
+        # nJoints is `config.nJoints` in the file (nullspace:61); the module globals sig / lastvec are built from it
+        ns = _NS(_extract(os.path.join(REF, "scripts", "nullspace"),
+                          ["restrict", "nullspace", "move_in_nullspace", "check_limits", "matrixrank", "sign", "sig", "lastvec"],
+                          preset={"nJoints": n}))
         from numpy import mat, eye
         P = mat(eye(6))
         rng = np.random.default_rng(7000 + n)
@@ -282,6 +265,29 @@ def make_nullspace_golden():
         out["n%d__lim_q" % n] = q
         out["n%d__lim_qdot" % n] = qdot
         out["n%d__lim_out" % n] = res
+    # (4) the raw sign LAPACK's SVD gives the unique null vector when its FIRST component is (nearly) zero: columns
+    # 1..6 are made dependent up to eps * (a random direction), so u_0 = O(eps) and the rule "first NON-NEGLIGIBLE
+    # component negative" is what decides.  Fresh state (sig = 1, lastvec = 0) for every case: nullspace() then
+    # returns the raw vector.
+    eps_list = [0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6, 1e-3]
+    rng = np.random.default_rng(7777)
+    Jz, Uz = [], []
+    for eps in eps_list:
+        for rep_ in range(4):
+            ns = _NS(_extract(os.path.join(REF, "scripts", "nullspace"),
+                              ["restrict", "nullspace", "move_in_nullspace", "check_limits", "matrixrank", "sign", "sig", "lastvec"],
+                              preset={"nJoints": 7}))
+            from numpy import mat, eye
+            J = _rand_jac(rng, 7)
+            coef = rng.normal(size=5)
+            J[:, 6] = J[:, 1:6] @ coef + eps * J[:, 0]   # J u = 0 with u = (eps, coef, -1) / |.|
+            basis = np.asarray(ns.nullspace(mat(eye(6)), mat(J)))
+            assert basis.shape[0] == 1, (eps, basis.shape)
+            Jz.append(J)
+            Uz.append(basis[0])
+    out["n7__zero_first_J"] = np.stack(Jz)
+    out["n7__zero_first_u"] = np.stack(Uz)
+    out["n7__zero_first_eps"] = np.repeat(eps_list, 4)
     np.savez(os.path.join(OUT, "nullspace_golden.npz"), **out)
     print("nullspace_golden.npz written; numpy", np.__version__)
 

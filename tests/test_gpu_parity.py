@@ -118,6 +118,68 @@ def test_c5_dual_arm_nullspace_joint_limit_task(env):
     assert np.abs(ref["qdot_null"]).max() > 1e-3
 
 
+def test_c5_full_size_lean_launch(env):
+    """C5 at BASELINE's full size -- 65 536 arms x 14 joints x 16 obstacles, float32 I/O -- through the launch the
+    bench times (qdot_out and status only: the LEAN kernel variant), every arm against the oracle."""
+    chain = env.robots.lwr_dual14()
+    w = env.synth.make_workload(chain, 65536, 16, seed=0, io_dtype=np.float32)
+    f = env.abi
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_JOINT_LIMIT_TASK | f.F_MIXER)
+    got, ref = _run_both(env, chain, params, w, np.float32, want=("qdot_out", "status"))
+    worst = _compare(got, ref, TOL32, ("qdot_out", "status"))
+    print("C5 full size worst errors", worst)
+    assert np.abs(ref["qdot_out"]).max() > 1.0
+
+
+def test_c3n_full_size_two_cycles(env):
+    """C3 with the nullspace module and the mixer on (the default process set, vfclik:95-97) at 65 536 arms, float32
+    I/O, LEAN launch: the first cycle takes the cold path of the null vector, the second (arms moved a little) the
+    warm-started one; both against the oracle that carries its own sign memory."""
+    chain = env.robots.lwr()
+    B = 65536
+    w = env.synth.make_workload(chain, B, 8, seed=0, io_dtype=np.float32)
+    f = env.abi
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER)
+    ctrl = np.random.default_rng(5).uniform(-1, 1, (B, 4)).astype(np.float32).astype(np.float64)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    states = env.oc.new_states(B, chain.n)
+    q = w["q"]
+    for cyc in range(3):
+        got = eng.step_host(q, null_control=ctrl, want=("qdot_out", "status"))
+        ref = env.oc.cycle_batch(chain, params, q, w["fields"], w["nfields"], null_control=ctrl, states=states, want=("qdot_out", "qdot_null", "status"))
+        _compare(got, ref, TOL32, ("qdot_out", "status"))
+        q = np.clip(q + 2e-3 * ref["qdot_out"], chain.q_lo, chain.q_hi).astype(np.float32).astype(np.float64)
+    assert np.abs(ref["qdot_null"]).max() > 0.1
+    eng.close()
+
+
+def test_c3d_full_size_fp64_io(env):
+    """C3's batch with float64 I/O (65 536 arms, 8 obstacles) at the float64 tolerance."""
+    chain = env.robots.lwr()
+    w = env.synth.make_workload(chain, 65536, 8, seed=0, io_dtype=np.float64)
+    params = env.abi.default_params()
+    got, ref = _run_both(env, chain, params, w, np.float64, want=("qdot_out", "status"))
+    _compare(got, ref, TOL64, ("qdot_out", "status"))
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_c4_one_shard_of_the_524288_arm_batch(env, rank):
+    """C4 = 524 288 arms over 8 GPUs with no collective on the data path: every rank computes a contiguous
+    slice of the batch with its own handle.  One GPU is here: it takes the slice of `rank` out of the global batch
+    (what bench.py's rank does with its own seed) and must reproduce the oracle's rows of exactly those arms."""
+    from vfclik_amd import sharding
+    chain = env.robots.lwr()
+    total, world = 524288, 8
+    lo, hi = sharding.shard_range(total, rank, world)
+    assert hi - lo == 65536
+    # the global batch is generated shard by shard (seed = global shard index), so no rank ever holds all of it
+    w = env.synth.make_workload(chain, hi - lo, 8, seed=100 + rank, io_dtype=np.float32)
+    params = env.abi.default_params()
+    got, ref = _run_both(env, chain, params, w, np.float32, want=("qdot_out", "status"))
+    _compare(got, ref, TOL32, ("qdot_out", "status"))
+
+
 @pytest.mark.parametrize("name,nobs", [("powercube6", 3), ("lwr", 2)])
 def test_other_joint_counts(env, name, nobs):
     chain = env.robots.by_name(name)
