@@ -225,6 +225,15 @@ int vfik_memcpy_d2h(vfik_handle* h, void* dst_host, const void* src_dev, size_t 
  * kernel really runs on.) */
 int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, float* ms_total);
 
+/* Small batches: lean launches (revolute chain of up to 7 joints, identity tool, unit weights, goal + integer-order
+ * decay repellers, no module flag, qdot_out / status only) of batches up to max_batch arms take a kernel that
+ * spreads each arm over eight lanes (BASELINE north_star's "wavefront per arm" mapping) instead
+ * of one lane per arm.  Default 4096, the measured crossover (profiles/, tools/ab_mapping.py), or the environment
+ * variable VFIK_SUB8_MAX_BATCH when the handle is created; 0 = never.  vfik_small_batch_launches: how many launches
+ * took that kernel so far. */
+int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch);
+long vfik_small_batch_launches(vfik_handle* h);
+
 /* introspection for tests / DESIGN.md: slots in use, bytes of device state */
 int vfik_slots_in_use(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);

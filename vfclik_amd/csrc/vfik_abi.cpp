@@ -51,6 +51,11 @@ int slots_of(int type) {
 
 struct vfik_handle {
     int device = 0, io_dtype = 32, n = 0, max_slots = 0, B = 0, Bpad = 0, block = 64;
+    // eight-lanes-per-arm kernel for lean launches of batches up to this size (vfik_set_small_batch_kernel,
+    // VFIK_SUB8_MAX_BATCH).  Measured crossover (tools/ab_mapping.py, float64 I/O, goal + 4 repellers): 3-7 % faster than
+    // one lane per arm up to 4 096 arms, equal at 8 192, 1.4x / 2.0x / 2.8x SLOWER at 16 384 / 32 768 / 65 536.
+    int sub8_max_batch = 4096;
+    long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
     size_t esz = 4;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -207,6 +212,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q_lo = io->q_lo;
     a.q_hi = io->q_hi;
     a.q_ref_out = io->q_ref ? io->q_ref_out : nullptr;
+    a.sub8_max_batch = h->sub8_max_batch;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -287,6 +293,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         int b = std::atoi(e);
         if (b == 64 || b == 128 || b == 192 || b == 256) h->block = b;  // tuning knob; LDS per block = waves x 27-56 KB
     }
+    if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = std::max(0, std::atoi(e));
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
@@ -681,7 +688,9 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     }
     a.n_cycles = n_cycles;
     a.q_out = q_out;
-    hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, stream);
+    int sub8 = 0;
+    hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, stream, &sub8);
+    h->sub8_launches += sub8;
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VFIK_OK;
 }
@@ -1011,6 +1020,15 @@ int vfik_debug_read_stamps(vfik_handle* h, unsigned long long* dst) {
 #endif
 
 int vfik_slots_in_use(vfik_handle* h) { return h ? h->slots_used : VFIK_E_ARG; }
+
+int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (max_batch < 0) return fail(VFIK_E_ARG, "max_batch must be >= 0");
+    h->sub8_max_batch = max_batch;
+    return VFIK_OK;
+}
+
+long vfik_small_batch_launches(vfik_handle* h) { return h ? h->sub8_launches : -1; }
 
 size_t vfik_device_bytes(vfik_handle* h) { return h ? h->dev_bytes : 0; }
 

@@ -114,6 +114,7 @@ struct KArgs {
     const void* q_lo;            // [B][n] this cycle's joint limits per arm (nullspace:167, joint_p_controller:80), or NULL:
     const void* q_hi;            //        the chain's static limits of KConst
     void* q_ref_out;             // [B][n] the joint controller's reference after its clamp (joint_p_controller:121), or NULL
+    int sub8_max_batch;          // batches up to this size take the eight-lanes-per-arm kernel when the launch is lean (0: never)
 };
 
 // size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest
@@ -124,7 +125,8 @@ double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params
 
 // Type-erased launchers (implemented in vfik_kernel.hip).  kargs points to a KArgs<nj>.
 uint32_t supported_joints_mask();
-hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream);
+// *sub8 (may be NULL) is set to 1 when the launch took the eight-lanes-per-arm kernel
+hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream, int* sub8 = nullptr);
 hipError_t launch_probe(int io_dtype, const void* pose, const void* goal, const void* slots, int B, long Bp, int slots_used,
                         double rot_slow, double cos_slow, void* out, hipStream_t stream);
 hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream);

@@ -1782,8 +1782,210 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EIGHT LANES PER ARM (small batches): the mapping BASELINE.json's north_star sketches -- an arm spread over the lanes of
+// a (sub-)wave with cross-lane exchange -- for the common lean launch (revolute chain of up to 7 joints, identity
+// tool, unit weights, goal + integer-order decay repellers, no module flag, qdot_out / status only).  A wave holds 8
+// arms; lane j of an arm's group of 8
+//   * computes sin / cos of joint j                                   (1 angle per lane instead of 7 in sequence),
+//   * evaluates the repellers j, j + 8, ...                           (1 slot per lane per round instead of 8),
+//   * stores joint j of the result;
+// the serial spine -- the chained joint transforms, the attractor, J J^T, the 6 x 6 LDL^T, the two triangular solves --
+// is replicated on all 8 lanes (it does not parallelise: DESIGN.md section 5.1), and the group exchanges through 1 KiB of
+// LDS per arm (sin / cos, the repellers' sum, the result).  With 4 096 arms the launch has 512 waves instead of 64.
+// Plain loads: a batch this small has no bandwidth to stage for.  Same arithmetic as cycle_kernel up to the order of
+// the field sum.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NJ>
+__global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
+    static_assert(NJ <= 8, "one lane per joint");
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 3, j = lane & 7;
+    const int arm_raw = blockIdx.x * 8 + g;
+    const bool live = arm_raw < a.B;
+    const int arm = live ? arm_raw : a.B - 1;  // every lane stays active for the exchanges; stores are masked
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    double* const L = reinterpret_cast<double*>(lds_all) + g * 128;  // this arm's 1 KiB
+    typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
+    const KcPtr kc = (KcPtr)(unsigned long long)a.kc;
+    const KConst<NJ>* const kv = static_cast<const KConst<NJ>*>(a.kc);  // the same block through vector loads (lane-indexed)
+    const long Bp = a.Bpad;
+    int status = 0;
+
+    // ---- loads: joint angle of this lane, goal block (every lane of the group), this lane's first repeller
+    const int jq = j < NJ ? j : NJ - 1;
+    const double qj = (double)static_cast<const T*>(a.q)[(long)arm * NJ + jq];
+    const double offj = kv->dh[jq].off;
+    const T* gg = static_cast<const T*>(a.goal) + (long)arm * 4;
+    double gq[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gq[4 * k + c] = (double)gg[(long)k * Bp * 4 + c];
+    }
+    const T* sl = static_cast<const T*>(a.slots) + (long)arm * 4;
+    auto load_slot = [&](int m, double* s8) {  // slot m of this arm: (x y z radius | safe order force type); past the end: force 0
+        const bool in = m < a.slots_used;
+        const long mm = in ? m : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s8[c] = (double)sl[(2 * mm) * Bp * 4 + c];
+            s8[4 + c] = (double)sl[(2 * mm + 1) * Bp * 4 + c];
+        }
+        if (!in) s8[6] = 0.0;
+    };
+    double s8[8];
+    load_slot(j, s8);
+
+    // ---- A3: sin / cos of joint j on lane j, exchanged through LDS
+    {
+        double sj, cj;
+        sincos_fast(qj + offj, sj, cj);
+        L[2 * j] = sj;
+        L[2 * j + 1] = cj;
+    }
+    __syncthreads();
+    double sn[NJ], cs[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) { sn[i] = L[2 * i]; cs[i] = L[2 * i + 1]; }
+    // the chain, replicated (constants through the scalar cache)
+    double R[9], p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = kc->base[4 * r + c];
+        p[r] = kc->base[4 * r + 3];
+    }
+    double Jm[NJ][6];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        Jm[i][3] = R[2]; Jm[i][4] = R[5]; Jm[i][5] = R[8];
+        Jm[i][0] = p[0]; Jm[i][1] = p[1]; Jm[i][2] = p[2];
+        const double ci = cs[i], si = sn[i], di = kc->dh[i].d, ai = kc->dh[i].a, ca = kc->dh[i].ca, sa = kc->dh[i].sa;
+        double xn[3], ym[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { xn[r] = __builtin_fma(ci, R[3 * r], xn[r]); ym[r] = __builtin_fma(ci, R[3 * r + 1], -ym[r]); }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = __builtin_fma(di, R[3 * r + 2], p[r]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { p[r] = __builtin_fma(ai, xn[r], p[r]); R[3 * r] = xn[r]; }
+        double t1[3], t2[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { t1[r] = sa * R[3 * r + 2]; t2[r] = sa * ym[r]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {  // geometric Jacobian at the flange
+        const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
+        const double cx = Jm[i][4] * dz - Jm[i][5] * dy, cy = Jm[i][5] * dx - Jm[i][3] * dz, cz = Jm[i][3] * dy - Jm[i][4] * dx;
+        Jm[i][0] = cx; Jm[i][1] = cy; Jm[i][2] = cz;
+    }
+
+    // ---- A5: the repellers, one per lane and round; the group's sum through LDS in a fixed order
+    double part[3] = {0.0, 0.0, 0.0};
+    const int n0 = a.fast_order;
+    for (int m0 = 0; m0 < a.slots_used; m0 += 8) {  // wave-uniform
+        if (m0 > 0) load_slot(m0 + j, s8);
+        const double dx = s8[0] - p[0], dy = s8[1] - p[1], dz = s8[2] - p[2];
+        const double di = fmin(rsqrt_1nr(dx * dx + dy * dy + dz * dz), 1.0 / D_FLOOR);
+        const double rb = (s8[3] + s8[4]) * di;
+        const double k = s8[6] * fmin(powi_uniform(rb, n0), MAG_CAP) * di;
+        part[0] += dx * k; part[1] += dy * k; part[2] += dz * k;
+    }
+    __syncthreads();  // (the sin / cos values have been read)
+    L[16 + 4 * j] = part[0]; L[16 + 4 * j + 1] = part[1]; L[16 + 4 * j + 2] = part[2];
+    __syncthreads();
+    double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0}, gdist[2];
+    {
+        double GR[9], Gp[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) GR[3 * r + c] = gq[4 * r + c];
+            Gp[r] = gq[4 * r + 3];
+        }
+        attractor(R, p, GR, Gp, gq[13], gq[14], kc->rot_slow, kc->cos_slow, gq[12] != 0.0, tot, sc, gdist);
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) { tot[0] += L[16 + 4 * l]; tot[1] += L[16 + 4 * l + 1]; tot[2] += L[16 + 4 * l + 2]; }
+    double tw[6];
+    {
+        double nt, nti, nr, nri;
+        sqrt_rsqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2], nt, nti);
+        sqrt_rsqrt(tot[3] * tot[3] + tot[4] * tot[4] + tot[5] * tot[5], nr, nri);
+        const double speed = gq[15];
+        const double kt = nt > EPS_LEN ? speed * sc[0] * nti : 0.0;
+        const double kr = nr > EPS_LEN ? speed * sc[1] * nri : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tw[k] = tot[k] * kt; tw[3 + k] = tot[3 + k] * kr; }
+    }
+
+    // ---- A7: damped least squares (replicated)
+    double A[6][6], dinv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) A[r][c] = r == c ? kc->lambda2 : 0.0;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(Jm[i][r], Jm[i][c], A[r][c]);
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+        double v[6];
+#pragma unroll
+        for (int k = 0; k < jj; ++k) v[k] = A[jj][k] * A[k][k];
+        double dj = A[jj][jj];
+#pragma unroll
+        for (int k = 0; k < jj; ++k) dj = __builtin_fma(-A[jj][k], v[k], dj);
+        A[jj][jj] = dj;
+        dinv[jj] = rcp_nr(dj);
+#pragma unroll
+        for (int k = 0; k < jj; ++k)
+#pragma unroll
+            for (int i = jj + 1; i < 6; ++i) A[i][jj] = __builtin_fma(-A[i][k], v[k], A[i][jj]);
+#pragma unroll
+        for (int i = jj + 1; i < 6; ++i) A[i][jj] *= dinv[jj];
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double t = tw[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
+        y[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] *= dinv[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double t = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k];
+        y[i] = t;
+    }
+    int nan = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        double qv = Jm[i][0] * y[0];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) qv = __builtin_fma(Jm[i][r], y[r], qv);
+        nan |= (int)(qv != qv);
+        L[64 + i] = qv;  // (all 8 lanes hold the same value)
+    }
+    if (nan) status |= VFIK_ST_NAN;
+    __syncthreads();
+    if (live && j < NJ) static_cast<T*>(a.qdot_out)[(long)arm * NJ + j] = (T)L[64 + j];
+    if (live && j == 0 && a.status) a.status[arm] = status;
+}
+
 template <typename T, int NJ, bool NS, bool PL>
-void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, int* sub8) {
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
     // one, the general path's code cost the straight-line launches 2.7 % (register allocation and layout).
     const bool fastf = a.fast_order >= 0;
@@ -1802,6 +2004,15 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
             }
             if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 0>), grid, blk, lds, stream, a);
             else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, 0>), grid, blk, lds, stream, a);
+            return;
+        }
+    }
+    if constexpr (PL && !NS && NJ <= 8) {
+        // small lean batches: eight lanes per arm (cycle_sub8_kernel).  VFIK_SUB8_MAX_BATCH = 0 switches it off.
+        if (lean && !a.q_out && a.n_cycles == 0 && a.qdot_out && a.B <= a.sub8_max_batch) {
+            const dim3 g8((a.B + 7) / 8), b8(64);
+            hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ>), g8, b8, 8 * 1024, stream, a);
+            if (sub8) *sub8 = 1;
             return;
         }
     }
@@ -1835,18 +2046,18 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
 }
 
 template <typename T, int NJ>
-hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream) {
+hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     KArgs a = a0;
     a.block = block;
     const dim3 grid((a.B + block - 1) / block), blk(block);
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     const bool ns = a.flags & VFIK_F_NULLSPACE;
     if (a.plain) {
-        if (ns) launch_v<T, NJ, true, true>(a, grid, blk, lds, stream);
-        else launch_v<T, NJ, false, true>(a, grid, blk, lds, stream);
+        if (ns) launch_v<T, NJ, true, true>(a, grid, blk, lds, stream, sub8);
+        else launch_v<T, NJ, false, true>(a, grid, blk, lds, stream, sub8);
     } else {
-        if (ns) launch_v<T, NJ, true, false>(a, grid, blk, lds, stream);
-        else launch_v<T, NJ, false, false>(a, grid, blk, lds, stream);
+        if (ns) launch_v<T, NJ, true, false>(a, grid, blk, lds, stream, sub8);
+        else launch_v<T, NJ, false, false>(a, grid, blk, lds, stream, sub8);
     }
     return hipGetLastError();
 }
@@ -1859,13 +2070,13 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream) {
 #ifdef VFIK_ONLY_NJ
 #define VFIK_CAT2(a, b) a##b
 #define VFIK_CAT(a, b) VFIK_CAT2(a, b)
-hipError_t VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ)(int io_dtype, const KArgs& kargs, int block, hipStream_t stream) {
-    return io_dtype == 32 ? launch_t<float, VFIK_ONLY_NJ>(kargs, block, stream) : launch_t<double, VFIK_ONLY_NJ>(kargs, block, stream);
+hipError_t VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ)(int io_dtype, const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
+    return io_dtype == 32 ? launch_t<float, VFIK_ONLY_NJ>(kargs, block, stream, sub8) : launch_t<double, VFIK_ONLY_NJ>(kargs, block, stream, sub8);
 }
 }  // namespace vfik
 #else  // VFIK_DISPATCH
 
-#define X(n) hipError_t launch_cycle_nj##n(int io_dtype, const KArgs& kargs, int block, hipStream_t stream);
+#define X(n) hipError_t launch_cycle_nj##n(int io_dtype, const KArgs& kargs, int block, hipStream_t stream, int* sub8);
 VFIK_NJ_LIST
 #undef X
 
@@ -1995,9 +2206,9 @@ uint32_t supported_joints_mask() {
     return m;
 }
 
-hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream) {
+hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
     switch (nj) {
-#define X(n) case n: return launch_cycle_nj##n(io_dtype, kargs, block, stream);
+#define X(n) case n: return launch_cycle_nj##n(io_dtype, kargs, block, stream, sub8);
         VFIK_NJ_LIST
 #undef X
         default: return hipErrorInvalidValue;

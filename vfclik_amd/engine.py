@@ -87,6 +87,8 @@ def load_library(path=None):
         "vfik_set_max_vel": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "vfik_probe_field": (C.c_int, [H, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_set_small_batch_kernel": (C.c_int, [H, C.c_int]),
+        "vfik_small_batch_launches": (C.c_long, [H]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
@@ -426,6 +428,14 @@ class Engine:
         self._chk(self.lib.vfik_set_arm_weights(self.h, int(first_arm), counts.pop(),
                                                 None if arrs[0] is None else arrs[0].ctypes.data,
                                                 None if arrs[1] is None else arrs[1].ctypes.data))
+
+    def set_small_batch_kernel(self, max_batch):
+        """Lean launches of batches up to max_batch arms take the eight-lanes-per-arm kernel (0 = never)."""
+        self._chk(self.lib.vfik_set_small_batch_kernel(self.h, int(max_batch)))
+
+    @property
+    def small_batch_launches(self):
+        return int(self.lib.vfik_small_batch_launches(self.h))
 
     def probe_field(self, pose_dev, v6_dev):
         """The field of every arm at a given pose (vf:469-503): device pose[B][16] -> v6[B][6]."""
