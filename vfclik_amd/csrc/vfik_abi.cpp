@@ -65,6 +65,7 @@ struct vfik_handle {
     // device state
     void* d_goal = nullptr;    // 4 quad planes
     void* d_slots = nullptr;   // 2*S quad planes
+    void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
     void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
     double tool_shared[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     int tool_per_arm = 0;
@@ -138,9 +139,13 @@ void put(std::vector<char>& buf, size_t idx, double v) {
 // (P * n_arms + j) * 4 + c): goal = 4 planes, slots = 2*S planes (vfik_kernel.h).
 template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
-                 std::vector<char>& goal, std::vector<char>& slots, std::vector<int>& used) {
+                 std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used) {
     goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
     slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
+    // compact image: a decay repeller needs 6 of its slot's 8 scalars (x y z radius safe | force; the decay order is
+    // one number for the batch on the straight-line path and the type is known), so two slots share three quads:
+    // (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1).  Slots of another type leave zeros (force 0): they force the general path.
+    fast.assign((size_t)3 * ((std::max(1, S) + 1) / 2) * n_arms * 4 * sizeof(T), 0);
     std::vector<int> order;
     for (int j = 0; j < n_arms; ++j) {
         const vfik_field* f = fields + (size_t)j * max_fields;
@@ -166,6 +171,13 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
             for (int e = 0; e < 6; ++e) put<T>(slots, at(0, e), fd.p[e]);
             put<T>(slots, at(0, 6), fd.force);
             put<T>(slots, at(0, 7), (double)fd.type);
+            if (fd.type == VFIK_FIELD_REPELLER) {
+                const int pair = m >> 1, half = m & 1;
+                for (int i = 0; i < 6; ++i) {
+                    const int e = 6 * half + i;  // position in the pair's 12 scalars
+                    put<T>(fast, ((size_t)(3 * pair + (e >> 2)) * n_arms + j) * 4 + (e & 3), i < 5 ? fd.p[i] : fd.force);
+                }
+            }
             for (int c = 1; c < ns; ++c) {
                 for (int e = 0; e < 6; ++e) {
                     const int pi = 6 * c + e;
@@ -192,6 +204,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q = io->q;
     a.goal = h->d_goal;
     a.slots = h->d_slots;
+    a.slots_fast = h->d_slots_fast;
     a.tool = h->d_tool;
     a.null_control = io->null_control;
     a.ext = h->d_ext;
@@ -302,6 +315,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
     if (dev_alloc(h, &h->d_goal, 4 * quad_plane, true)) return bail("alloc goal");
     if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane, true)) return bail("alloc slots");  // >= 1 slot: the prefetch reads slot 0
+    if (dev_alloc(h, &h->d_slots_fast, (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane, true)) return bail("alloc compact slots");
     if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float), true)) return bail("alloc lastvec");
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
     if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints) + 2048, true)) return bail("alloc kconst");  // + slack: the kinematics block is copied in whole 1-KiB rows
@@ -332,7 +346,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_slots_fast, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
     for (auto& ps : h->pipe) {
@@ -512,11 +526,11 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         if (need > h->max_slots) return fail(VFIK_E_ARG, "arm %d needs %d slots, handle capacity is %d", first_arm + j, need, h->max_slots);
     }
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<char> goal, slots;
+    std::vector<char> goal, slots, fast;
     std::vector<int> used(n_arms);
     const int S = h->max_slots;
-    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, used);
-    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, used);
+    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used);
+    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used);
     const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
     char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
@@ -525,6 +539,8 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     if (S > 0) {
         char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
+        char* df = static_cast<char*>(h->d_slots_fast) + (size_t)first_arm * qb;
+        HIP_TRY(hipMemcpy2DAsync(df, pitch, fast.data(), w, w, (size_t)((S + 1) / 2) * 3, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int j = 0; j < n_arms; ++j) {

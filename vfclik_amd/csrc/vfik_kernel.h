@@ -20,6 +20,8 @@ namespace vfik {
 //   q, qdot_*, qdist      [B][n]      batch-major (the reference's bottles: n doubles per arm)
 //   pose, pose_nt         [B][16]
 //   goal                  4 planes    frame rows 0,1,2 | (present, slow-down, force, speedScale of the arm)
+//   slots_fast            3 ceil(S/2) planes  decay repellers only, two slots in three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1);
+//                                     what the straight-line field path reads (24 instead of 32 bytes a slot at float I/O)
 //   slots                 2S planes   slot m = planes 2m, 2m+1 = (p0 p1 p2 p3 | p4 p5 force type);
 //                                     type -1 = continuation of the previous slot (p6..p11 / p12..p16),
 //                                     type 0 = empty
@@ -84,6 +86,7 @@ struct KArgs {
     const void* q;
     const void* goal;
     const void* slots;
+    const void* slots_fast;  // compact repeller image of the straight-line path: 3 quad planes per pair of slots (vfik_abi.cpp, pack_fields)
     const void* tool;
     const void* null_control;
     const void* ext;

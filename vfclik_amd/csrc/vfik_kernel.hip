@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
-    asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots),
+    asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots), "s"(a.slots_fast),
                  "s"(a.tool), "s"(a.mixw), "s"(a.kc));
     const int arm = blockIdx.x * a.block + threadIdx.x;
     const long Bs = a.B;
@@ -609,20 +609,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // (tools/ubench_loads.hip), and spreading them out lets that queue drain under arithmetic.
     const int npre = a.slots_used < PRE ? a.slots_used : PRE;
     const char* const gg = static_cast<const char*>(a.goal) + (long)arm * QB;
-    const char* const sg = static_cast<const char*>(a.slots) + (long)arm * QB;
-    auto issue_slot_quad = [&](int idx) {  // idx in [0, 2 * PRE): quad idx & 1 of slot idx >> 1
-        // slots past the ones in use re-request slot 0 (cache hit) and are masked below, so the
+    // The straight-line path reads the COMPACT repeller image (two slots in three quads, vfik_kernel.h): a chunk of PRE
+    // slots is QPC = 3 PRE / 2 quads instead of 2 PRE -- a quarter fewer bytes and requests for what is, at these
+    // batches, the longest wait of the wave (the slots' data is the last to arrive).
+    constexpr int QPC = FASTF ? 3 * PRE / 2 : 2 * PRE;       // slot quads per chunk
+    const char* const sg = static_cast<const char*>(FASTF ? a.slots_fast : a.slots) + (long)arm * QB;
+    auto issue_slot_quad = [&](int idx) {  // idx in [0, QPC): quad idx of the first chunk
+        // quads past the slots in use re-request plane 0 (cache hit) and are masked below, so the
         // number of outstanding requests is a compile-time constant for the counted waits
-        const int m = idx >> 1;
-        const char* sm = sg + (m < npre ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+        const bool in = FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre;
+        stage_quad<T>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::ROW_SLOT + idx * Q16);
     };
-    constexpr int N_SLOT = 2 * PRE * Q16;                   // requests issued after the goal
+    constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
     // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
     // slot quads are requested into that wait, the remaining slot quads between the joints.
     // (long chains have two rows of constants and five q pieces in front already: nothing early there, C5 -1.3 %)
     constexpr int EARLY_Q = NJ >= 10 ? 0 : 6;
-    constexpr int SLOTQ_PER_JOINT = (2 * PRE - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
+    constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
 #pragma unroll
     for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
 #pragma unroll
@@ -739,7 +742,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (ROLL && !first && a.slots_used > PRE) {  // the rows hold the last chunk of the previous cycle
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int idx = 0; idx < 2 * PRE; ++idx) issue_slot_quad(idx);
+        for (int idx = 0; idx < QPC; ++idx) issue_slot_quad(idx);
     }
     {
         // No libm fallback: the three-part reduction keeps full accuracy to |angle| ~ 1e5 rad and degrades
@@ -789,7 +792,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
-            if (first && EARLY_Q + i * SLOTQ_PER_JOINT + k < 2 * PRE) issue_slot_quad(EARLY_Q + i * SLOTQ_PER_JOINT + k);
+            if (first && EARLY_Q + i * SLOTQ_PER_JOINT + k < QPC) issue_slot_quad(EARLY_Q + i * SLOTQ_PER_JOINT + k);
     }
     if (!PLAIN) {   // trailing z-screw of the last fixed transform
         const double tc = klc->tail_c, ts = klc->tail_s, te = klc->tail_e;
@@ -1017,22 +1020,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
                 double dx[PRE], dy[PRE], dz[PRE], rs[PRE], fk[PRE];
 #pragma unroll
-                for (int m = 0; m < PRE; ++m) {
-                    double s0[4], s1[4];
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
-                    read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
-                    dx[m] = s0[0] - pt[0];
-                    dy[m] = s0[1] - pt[1];
-                    dz[m] = s0[2] - pt[2];
-                    rs[m] = s0[3] + s1[0];
-                    fk[m] = m < ncur ? s1[2] : 0.0;
+                for (int k = 0; k < PRE / 2; ++k) {  // a pair of slots = three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1)
+                    double v[12];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) read_quad<T>(region, Stage<T>::ROW_SLOT + (3 * k + u) * Q16, lanec, v + 4 * u);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int m = 2 * k + hf;
+                        dx[m] = v[6 * hf] - pt[0];
+                        dy[m] = v[6 * hf + 1] - pt[1];
+                        dz[m] = v[6 * hf + 2] - pt[2];
+                        rs[m] = v[6 * hf + 3] + v[6 * hf + 4];
+                        fk[m] = m < ncur ? v[6 * hf + 5] : 0.0;
+                    }
                 }
                 if (c0 + PRE < a.slots_used) {  // wave-uniform
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the rows have returned
 #pragma unroll
-                    for (int idx = 0; idx < 2 * PRE; ++idx) {
-                        const int m = c0 + PRE + (idx >> 1);
-                        const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+                    for (int idx = 0; idx < QPC; ++idx) {
+                        const int m = c0 + PRE + 2 * (idx / 3);  // first slot of the quad's pair
+                        const char* sm = sg + (m < a.slots_used ? (long)((c0 + PRE) / 2 * 3 + idx) * planeB : 0);
                         stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
                     }
                 }
