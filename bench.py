@@ -13,8 +13,8 @@ this with 8 ranks, so scaling is weak and there is no collective on the data pat
 Timing (median and p10/p90): the timed region -- barrier, synchronize, stamp, EXACTLY K
 launches, synchronize, stamp -- is repeated R times (--reps); the collective that takes the maximum over
 ranks runs after the last repetition, outside every stamped interval.  `value` comes from the MEDIAN
-repetition; p10/p90 are printed next to it.  HIP events on the launch stream bracket the same K launches of
-every repetition and give the kernel's launch period for `roofline`.
+repetition; p10/p90 are printed next to it.  R further repetitions, interleaved with those, bracket the same K
+launches with HIP events on the launch stream and give the kernel's launch period for `roofline`.
 
 Rank 0 prints one JSON line.  `roofline` prices the kernel against HBM with the ALGORITHMIC bytes of
 SURVEY 8d (384 B per cycle at C3); `cpu_baseline` (N = 1 only) times the CPU oracle (oracle/, the build's
@@ -255,25 +255,35 @@ def worker(args):
         eng.step(io)
     torch.cuda.synchronize()
 
+    # Repetitions alternate between two kinds: WALL repetitions (even) carry nothing but the K launches between the
+    # stamps and give `value`; EVENT repetitions (odd) bracket the same K launches with HIP events on the launch stream
+    # and give the kernel's launch period for `roofline`.  (Recording two timing events costs a 20-launch region
+    # ~20 us -- 1 us a step -- which is why they are kept out of the interval that `value` comes from.)
     K, R = args.steps, args.reps
     wall_s, ev_pairs, enqueue_s = [], [], []
-    for _ in range(R):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(2 * R):
+        with_events = r % 2 == 1
+        if with_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()                      # ranks start together; the barrier itself is NOT inside the interval
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ev0.record(stream)
+        if with_events:
+            ev0.record(stream)
         for _ in range(K):
             eng.step(io)
             if args.sync_each:
                 torch.cuda.synchronize()
         t_enq = time.perf_counter()
-        ev1.record(stream)
+        if with_events:
+            ev1.record(stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        wall_s.append(t1 - t0)
-        enqueue_s.append(t_enq - t0)
-        ev_pairs.append((ev0, ev1))
+        if with_events:
+            ev_pairs.append((ev0, ev1))
+        else:
+            wall_s.append(t1 - t0)
+            enqueue_s.append(t_enq - t0)
     ev_ms = [a.elapsed_time(b) for a, b in ev_pairs]  # same stream as the launches
     own_wall_s = list(wall_s)
     wall_s = reduce_max(wall_s)        # per repetition: the slowest rank
@@ -397,7 +407,7 @@ def worker(args):
                          "algorithmic_bytes_per_cycle": bytes_per_cycle,
                          "us_per_launch_hip_events": us_med,
                          "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),
-                         "launches_timed": R * K},
+                         "launches_timed": R * K, "timed": "R repetitions of K launches between two HIP events on the launch stream, interleaved with the wall-clock repetitions"},
         }
         if args.sync_each:
             line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"

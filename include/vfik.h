@@ -116,7 +116,15 @@ int vfik_reset_state(vfik_handle* h);
 /* Buffers of one control cycle.  NULL = not wanted / not supplied. */
 typedef struct vfik_io {
     const void* q;            /* in  [B][n]   /qIn, /nullspace/qin, /debug/qin (vf:312, nullspace:162) */
-    const void* null_control; /* in  [B][4]   /nullspace/control (nullspace:169-173); NULL = zeros */
+    const void* null_control; /* in  [B][4]   /nullspace/control (nullspace:169-173); NULL = zeros.  HONOURED ONLY where the
+                                 nullspace is one-dimensional (7 joints at a regular pose: element 0 scales the unique
+                                 basis vector, nullspace:110-117).  With nullity >= 2 -- every chain of 8+ joints, a
+                                 7-joint arm at a rank-deficient pose -- the reference moves along whatever basis LAPACK's
+                                 SVD returns inside the nullspace, which cannot be restated: the arm then gets
+                                 VFIK_ST_NULL_AMBIGUOUS, /control contributes nothing, and qdot_null carries the
+                                 joint-limit task alone.  What IS reproduced there is the subspace: the reference's
+                                 command lies in null(J) and the projector used here leaves it unchanged
+                                 (tests/test_oracle_golden.py, the reference's own n = 14 outputs) */
     void* qdot_vf;            /* out [B][n]   /vectorField/qdotOut (vf:462-466) */
     void* qdot_null;          /* out [B][n]   /nullspace/qdotout (nullspace:180-184) */
     void* qdot_out;           /* out [B][n]   mixed (+limited) command (bridge:626); = qdot_vf without the mixer */

@@ -84,7 +84,8 @@ typedef struct vfik_params {
 enum {
     VFIK_ST_NAN = 1 << 0,            /* a NaN reached a joint command (command_mixer.py:71-75 only prints) */
     VFIK_ST_LIMIT_STOP = 1 << 1,     /* nullspace look-ahead crossed a joint limit -> null command zeroed (nullspace:120-131) */
-    VFIK_ST_NULL_AMBIGUOUS = 1 << 2, /* nullity != 1: the reference's SVD basis is not unique; /control ignored */
+    VFIK_ST_NULL_AMBIGUOUS = 1 << 2, /* nullity != 1: the reference's SVD basis is not unique; /control is NOT honoured for
+                                        this arm in this cycle (a declared functional gap, see vfik_io.null_control) */
     VFIK_ST_LIMITED = 1 << 3,        /* bridge limiter scaled the command (bridge:190-191) */
     VFIK_ST_JOINT_AT_GOAL = 1 << 4   /* /jpctrl/at_goal (joint_p_controller:134-146): every ref_i - q_i < jp_delta
                                         (signed, as the reference compares it); only with io->q_ref */
