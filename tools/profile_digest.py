@@ -26,8 +26,8 @@ def main():
         tr = one(os.path.join(d, "trace_" + w, "*", "*kernel_trace.csv"))
         if not st:
             continue
-        row = [r for r in csv.DictReader(open(st)) if "cycle_kernel" in r["Name"]][0]
-        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr)) if "cycle_kernel" in r["Kernel_Name"]]
+        row = [r for r in csv.DictReader(open(st)) if "::cycle_" in r["Name"]][0]
+        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr)) if "::cycle_" in r["Kernel_Name"]]
         line = json.loads(open(os.path.join(d, "bench_under_rocprof_%s.json" % w)).read().strip().splitlines()[-1])
         plain = json.loads(open(os.path.join(d, "bench_%s.json" % w)).read().strip().splitlines()[-1])
         mean = float(row["AverageNs"])
@@ -46,7 +46,7 @@ def main():
             if not f:
                 continue
             for r in csv.DictReader(open(f)):
-                if "cycle_kernel" not in r["Kernel_Name"]:
+                if "::cycle_" not in r["Kernel_Name"]:
                     continue
                 kname = r["Kernel_Name"]
                 per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
@@ -72,7 +72,7 @@ def main():
             continue
         per = {}
         for r in csv.DictReader(open(f)):
-            if "cycle_kernel" not in r["Kernel_Name"]:
+            if "::cycle_" not in r["Kernel_Name"]:
                 continue
             per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
