@@ -284,3 +284,27 @@ def test_changed_batch_mixer_weights_reach_arms_with_their_own_bridge_state(env)
     again = eng.step_host(w["q"], want=("qdot_out",))
     assert np.abs(again["qdot_out"] - exp).max() < 1e-12
     eng.close()
+
+
+@pytest.mark.parametrize("robot", ["lwr", "lwr_dual14"])
+def test_rollout_leaves_gated_arms_alone(env, robot):
+    """vfik_rollout with the fresh-q gate: gated arms are not integrated -- their q_out / qdot_out rows keep what the
+    caller put there -- while the others equal a rollout without the gate (in-kernel loop for 7 joints, stepped
+    launches for 14)."""
+    chain = env.robots.by_name(robot)
+    B, K = 96, 25
+    w = env.synth.make_workload(chain, B, 2, seed=17, io_dtype=np.float64)
+    f = env.abi
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=2, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    full = eng.rollout_host(w["q"], K, 2e-3, want=("qdot_out", "status"))
+    eng.reset_state()
+    active = np.arange(B) % 3 != 0
+    got = eng.rollout_host(w["q"], K, 2e-3, want=("qdot_out", "status"), active=active)
+    # (the gated launch is another kernel variant than the lean one: same arithmetic, another schedule -- not bit-equal)
+    assert np.abs(got["q"][active] - full["q"][active]).max() < 1e-12
+    assert np.abs(got["qdot_out"][active] - full["qdot_out"][active]).max() < 1e-10
+    assert np.all(got["q"][~active] == 0.0) and np.all(got["qdot_out"][~active] == 0.0)  # the zero-filled host rows came back
+    assert np.abs(full["q"] - w["q"]).max() > 1e-3
+    eng.close()
