@@ -56,6 +56,7 @@ struct vfik_handle {
     // one lane per arm up to 4 096 arms, equal at 8 192, 1.4x / 2.0x / 2.8x SLOWER at 16 384 / 32 768 / 65 536.
     int sub8_max_batch = 4096;
     long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
+    int n_simd = 1024;       // 4 per CU of this device
     size_t esz = 4;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -226,6 +227,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q_hi = io->q_hi;
     a.q_ref_out = io->q_ref ? io->q_ref_out : nullptr;
     a.sub8_max_batch = h->sub8_max_batch;
+    a.n_simd = h->n_simd;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -310,6 +312,10 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
+    }
     const size_t B = batch;
     h->Bpad = (batch + 63) / 64 * 64;
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;

@@ -430,9 +430,13 @@ template <typename T> struct Stage {
     // (measured 15.3 us instead of ~8 for the C3 batch).
     static constexpr int PRE = sizeof(T) == 8 ? 4 : 8;
     static constexpr int Q16 = (int)sizeof(T) / 4;           // 16-B pieces per quad
-    static constexpr int QROWS = (3 + 4 + 2 * PRE + 2) * Q16;  // 1 KiB rows
-    static constexpr int ROW_TOOL = 0, ROW_GOAL = 3 * Q16, ROW_SLOT = 7 * Q16, ROW_MIXW = (7 + 2 * PRE) * Q16;
     static constexpr int QBYTES = 4 * (int)sizeof(T);        // bytes of one quad
+    static constexpr int QSTEP = Q16 * 1024;                 // LDS bytes of one staged quad (a 1-KiB row per 16 bytes per lane)
+    static constexpr int QPCF = 3 * PRE / 2;                 // quads of one chunk of the compact repeller image
+    // Region of one wave, in the order [goal 4 | slot quads 0 .. QPCF-1 | q | kinematics | table] -- that much is all a LEAN
+    // launch on the straight-line path touches (`lean_bytes`: 19.75 KB for 7 joints with float I/O, eight waves per CU) --
+    // then [slot quads QPCF .. 2 PRE - 1 | tool 3 | mixer weights 2] for the general path and the optional per-arm inputs.
+    static constexpr int GOAL_OFF = 0, SLOT_OFF = 4 * QSTEP, Q_OFF = (4 + QPCF) * QSTEP;
     // q is batch-major ([B][n]): a lane's n values are contiguous and travel as 16-byte pieces plus a
     // remainder of one to three 4-byte pieces (a 12-byte LDS-DMA did not land lane-linear on gfx950)
     __host__ __device__ static constexpr int qbytes(int nj) { return nj * (int)sizeof(T); }
@@ -440,9 +444,15 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
     __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4) * 8 + 1023) / 1024; }
-    __host__ __device__ static constexpr int kin_off(int nj) { return QROWS * 1024 + qregion(nj); }
+    __host__ __device__ static constexpr int kin_off(int nj) { return Q_OFF + qregion(nj); }
     __host__ __device__ static constexpr int tab_off(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }  // sin / cos table, 1 KiB
-    __host__ __device__ static constexpr int bytes(int nj) { return tab_off(nj) + 1024; }
+    __host__ __device__ static constexpr int lean_bytes(int nj) { return tab_off(nj) + 1024; }
+    __host__ __device__ static constexpr int slot_off(int idx, int nj) {  // slot quad idx of the staged chunk
+        return idx < QPCF ? SLOT_OFF + idx * QSTEP : lean_bytes(nj) + (idx - QPCF) * QSTEP;
+    }
+    __host__ __device__ static constexpr int tool_off(int nj) { return lean_bytes(nj) + (2 * PRE - QPCF) * QSTEP; }
+    __host__ __device__ static constexpr int mixw_off(int nj) { return tool_off(nj) + 3 * QSTEP; }
+    __host__ __device__ static constexpr int bytes(int nj) { return mixw_off(nj) + 2 * QSTEP; }
 };
 
 // LDS byte address (relative to the q area) of byte b of this lane's q vector
@@ -458,23 +468,23 @@ __device__ __forceinline__ int q_lds_off(int b, int lane) {
 typedef __attribute__((address_space(1))) const void* GPtr;
 typedef __attribute__((address_space(3))) void* LPtr;
 
-// one quad plane: this lane's quad (QBYTES at gsrc) -> rows [row, row + Q16) of the region
+// one quad plane: this lane's quad (QBYTES at gsrc) -> the Q16 1-KiB rows at byte offset `off` of the region
 template <typename T>
-__device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int row) {
-    __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + row * 1024), 16, 0, 0);
-    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + (row + 1) * 1024), 16, 0, 0);
+__device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int off) {
+    __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + off), 16, 0, 0);
+    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + off + 1024), 16, 0, 0);
 }
 
 template <typename T>
-__device__ __forceinline__ void read_quad(const char* region, int row, int lane, double* out) {
+__device__ __forceinline__ void read_quad(const char* region, int off, int lane, double* out) {
     if (Stage<T>::Q16 == 1) {
         typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 v = *reinterpret_cast<const f4*>(region + row * 1024 + lane * 16);
+        const f4 v = *reinterpret_cast<const f4*>(region + off + lane * 16);
         out[0] = (double)v.x; out[1] = (double)v.y; out[2] = (double)v.z; out[3] = (double)v.w;
     } else {
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2 lo = *reinterpret_cast<const d2*>(region + row * 1024 + lane * 16);
-        const d2 hi = *reinterpret_cast<const d2*>(region + (row + 1) * 1024 + lane * 16);
+        const d2 lo = *reinterpret_cast<const d2*>(region + off + lane * 16);
+        const d2 hi = *reinterpret_cast<const d2*>(region + off + 1024 + lane * 16);
         out[0] = lo.x; out[1] = lo.y; out[2] = hi.x; out[3] = hi.y;
     }
 }
@@ -485,12 +495,13 @@ template <typename T> struct SlotGlobal {
     __device__ __forceinline__ double operator()(int m, int e) const { return slot_elem(sq, Q, m, e); }
 };
 template <typename T> struct SlotLds {
-    const char* region; int lane;  // the wave's staging region: slot m sits in quads 2m, 2m + 1 of the slot rows (m < PRE)
+    const char* region; int lane; int nj;  // the wave's staging region: slot m sits in slot quads 2m, 2m + 1 (m < PRE)
     __device__ __forceinline__ double operator()(int m, int e) const {
         const int quad = 2 * m + (e >> 2), c = e & 3;
+        const int off = Stage<T>::slot_off(quad, nj);
         if (Stage<T>::Q16 == 1)
-            return (double)*reinterpret_cast<const float*>(region + (Stage<T>::ROW_SLOT + quad) * 1024 + lane * 16 + c * 4);
-        return *reinterpret_cast<const double*>(region + (Stage<T>::ROW_SLOT + 2 * quad + (c >> 1)) * 1024 + lane * 16 + (c & 1) * 8);
+            return (double)*reinterpret_cast<const float*>(region + off + lane * 16 + c * 4);
+        return *reinterpret_cast<const double*>(region + off + (c >> 1) * 1024 + lane * 16 + (c & 1) * 8);
     }
 };
 
@@ -565,7 +576,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const int lane = threadIdx.x & 63;
     // wave-uniform by construction; say so, or every LDS destination goes through a VGPR + readfirstlane
-    char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * Stage<T>::bytes(NJ);
+    // (LEAN launches run the straight-line path and touch only the head of the region: their waves are packed closer)
+    constexpr int REGION_BYTES = (LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);
+    char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * REGION_BYTES;
     const long Bp = a.Bpad;
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
     constexpr int PRE = Stage<T>::PRE;
@@ -587,16 +600,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stage_quad<T>(tg + k * planeB, region, Stage<T>::ROW_TOOL + k * Q16);
+        for (int k = 0; k < 3; ++k) stage_quad<T>(tg + k * planeB, region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP);
     }
     if (a.mixw) {  // per-arm mixer weights ([2][Bpad] quads: w0..w3 | w4 w5 - -); else KConst::mix_w
         const char* mg = static_cast<const char*>(a.mixw) + (long)arm * QB;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) stage_quad<T>(mg + k * planeB, region, Stage<T>::ROW_MIXW + k * Q16);
+        for (int k = 0; k < 2; ++k) stage_quad<T>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
     {
         const char* qg = static_cast<const char*>(a.q) + (long)arm * NJ * sizeof(T);
-        char* qrow = region + Stage<T>::QROWS * 1024;
+        char* qrow = region + Stage<T>::Q_OFF;
         constexpr int n16 = Stage<T>::q16(NJ), rem = Stage<T>::qrem(NJ);
 #pragma unroll
         for (int i = 0; i < n16; ++i) __builtin_amdgcn_global_load_lds((GPtr)(qg + i * 16), (LPtr)(qrow + i * 1024), 16, 0, 0);
@@ -618,7 +631,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // quads past the slots in use re-request plane 0 (cache hit) and are masked below, so the
         // number of outstanding requests is a compile-time constant for the counted waits
         const bool in = FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre;
-        stage_quad<T>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::ROW_SLOT + idx * Q16);
+        stage_quad<T>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::slot_off(idx, NJ));
     };
     constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
     // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
@@ -627,7 +640,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     constexpr int EARLY_Q = NJ >= 10 ? 0 : 6;
     constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::ROW_GOAL + k * Q16);
+    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
@@ -638,7 +651,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
     STAMP(2);
     {
-        const char* qrow = region + Stage<T>::QROWS * 1024;
+        const char* qrow = region + Stage<T>::Q_OFF;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             if (Q16 == 1) {
@@ -867,7 +880,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         double tl[12];
         if (a.tool_stride) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::ROW_TOOL + k * Q16, lanec, tl + 4 * k);
+            for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP, lanec, tl + 4 * k);
         } else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
@@ -989,7 +1002,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     {
         double gq[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::ROW_GOAL + k * Q16, lanec, gq + 4 * k);
+        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP, lanec, gq + 4 * k);
         speed = gq[15];
         {   // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, speedScale]
             double GR[9], Gp[3];
@@ -1023,7 +1036,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int k = 0; k < PRE / 2; ++k) {  // a pair of slots = three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1)
                     double v[12];
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) read_quad<T>(region, Stage<T>::ROW_SLOT + (3 * k + u) * Q16, lanec, v + 4 * u);
+                    for (int u = 0; u < 3; ++u) read_quad<T>(region, Stage<T>::slot_off(3 * k + u, NJ), lanec, v + 4 * u);
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const int m = 2 * k + hf;
@@ -1040,7 +1053,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < QPC; ++idx) {
                         const int m = c0 + PRE + 2 * (idx / 3);  // first slot of the quad's pair
                         const char* sm = sg + (m < a.slots_used ? (long)((c0 + PRE) / 2 * 3 + idx) * planeB : 0);
-                        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+                        stage_quad<T>(sm, region, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 double di[PRE], rb[PRE], rp[PRE];
@@ -1085,7 +1098,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             // PRE slots are read from the rows staged in LDS during the kinematics -- read from memory, every
             // slot cost a round trip of its own (C3 with one odd arm: 10.9 us per launch) -- the rest, and
             // entries that would straddle the staged window, from the quad planes.
-            const SlotLds<T> rl{region, lanec};
+            const SlotLds<T> rl{region, lanec, NJ};
             const double rs = kc->rot_slow, csl = kc->cos_slow;
             for (int c0 = 0; c0 < a.slots_used; c0 += PRE) {  // chunks of PRE slots through the staged rows
                 if (c0 > 0) {  // (no overlap with the previous chunk's arithmetic here: its entries read the rows lazily)
@@ -1094,7 +1107,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < 2 * PRE; ++idx) {
                         const int m = c0 + (idx >> 1);
                         const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-                        stage_quad<T>(sm, region, Stage<T>::ROW_SLOT + idx * Q16);
+                        stage_quad<T>(sm, region, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 VFIK_WAIT_VM(0);
@@ -1112,8 +1125,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                     for (int m = 0; m < PRE; ++m) {
                         double s0[4], s1[4];
-                        read_quad<T>(region, Stage<T>::ROW_SLOT + 2 * m * Q16, lanec, s0);
-                        read_quad<T>(region, Stage<T>::ROW_SLOT + (2 * m + 1) * Q16, lanec, s1);
+                        read_quad<T>(region, Stage<T>::slot_off(2 * m, NJ), lanec, s0);
+                        read_quad<T>(region, Stage<T>::slot_off(2 * m + 1, NJ), lanec, s1);
                         const int n = (int)s1[1];
                         const bool ok = m < ncur && (int)s1[3] == VFIK_FIELD_REPELLER && (double)n == s1[1] && n >= 0 && n < 128;
                         dx[m] = s0[0] - pt[0]; dy[m] = s0[1] - pt[1]; dz[m] = s0[2] - pt[2];
@@ -1470,8 +1483,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     double mw[8];  // this arm's bridge state: mixer weights 0..5, limiter max_vel 6 (per-arm quads, else the batch's)
     if (a.flags & (VFIK_F_MIXER | VFIK_F_LIMITER)) {
         if (a.mixw) {
-            read_quad<T>(region, Stage<T>::ROW_MIXW, lanec, mw);
-            read_quad<T>(region, Stage<T>::ROW_MIXW + Q16, lanec, mw + 4);
+            read_quad<T>(region, Stage<T>::mixw_off(NJ), lanec, mw);
+            read_quad<T>(region, Stage<T>::mixw_off(NJ) + Stage<T>::QSTEP, lanec, mw + 4);
         } else {
 #pragma unroll
             for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = kc->mix_w[k];
@@ -1996,6 +2009,11 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
     // one, the general path's code cost the straight-line launches 2.7 % (register allocation and layout).
     const bool fastf = a.fast_order >= 0;
+    // LEAN launches touch only the head of the region.  They ask for no more than that while the launch is at most one
+    // wave per SIMD (C5 -2 %, C3N -0.6 %, C3 +-0 at 65 536 arms); beyond, the full size keeps the launch in rounds of one
+    // wave per SIMD -- with eight waves resident per CU a 131 072-arm launch took 12.5 instead of 11.0 us (two waves
+    // per SIMD compete for the same HBM time; profiles/r02_batch_scaling.txt).
+    const size_t lds_lean = ((long)grid.x * (blk.x / 64) <= (long)a.n_simd) ? (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ) : lds;
     bool lean = false;
     if constexpr (PL)
         lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.ext && !a.q_ref && !a.q_cmded &&
@@ -2005,7 +2023,7 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         if (a.n_cycles > 0) {
             if constexpr (PL) {
                 if (lean) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 1>), grid, blk, lds, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 1>), grid, blk, lds_lean, stream, a);
                     return;
                 }
             }
@@ -2030,20 +2048,20 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
             if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds_lean, stream, a);
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds_lean, stream, a);
                     return;
                 }
             }
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds, stream, a);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds_lean, stream, a);
             return;
         }
         if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
             if (lean) {
-                hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds, stream, a);
+                hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds_lean, stream, a);
                 return;
             }
         }
