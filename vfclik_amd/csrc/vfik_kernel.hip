@@ -2073,6 +2073,8 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
 template <typename T, int NJ>
 hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     KArgs a = a0;
+    // (VFIK_BLOCK is a tuning knob: a block's waves must fit the CU's 160 KB of LDS with their regions)
+    while (block > 64 && (size_t)(block / 64) * Stage<T>::bytes(NJ) > 160u * 1024u) block -= 64;
     a.block = block;
     const dim3 grid((a.B + block - 1) / block), blk(block);
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
