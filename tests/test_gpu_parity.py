@@ -256,6 +256,23 @@ def test_all_primitive_types_ragged(env):
     assert np.all(got["qdot_out"][empty] == 0.0)  # only the seed field (type 0): no motion (vf:148-151)
 
 
+@pytest.mark.parametrize("robot,flags,dt,tol", [("lwr", 0, np.float64, TOL64), ("lwr", 5, np.float32, TOL32),
+                                                 ("lwr_dual14", 7, np.float64, TOL64), ("lwr_dual14", 0, np.float32, TOL32)])
+def test_general_field_path_lean_launch(env, robot, flags, dt, tol):
+    """Mixed primitive types (attractors, funnels, hemispheres, repellers of several orders; ragged) with nothing but
+    qdot_out / status asked for: the LEAN variant of the general field path, 7 and 14 joints."""
+    chain = env.robots.by_name(robot)
+    w = _mixed_fields(env, chain, 1024, seed=33)
+    for k in ("q",):
+        w[k] = w[k].astype(dt).astype(np.float64)
+    w["fields"]["p"] = w["fields"]["p"].astype(dt).astype(np.float64)
+    w["fields"]["force"] = w["fields"]["force"].astype(dt).astype(np.float64)
+    params = env.abi.default_params(flags=flags)
+    got, ref = _run_both(env, chain, params, w, dt, want=("qdot_out", "status"), max_slots=24)
+    _compare(got, ref, tol, ("qdot_out", "status"))
+    assert np.abs(ref["qdot_out"]).max() > 0.1
+
+
 def test_fractional_decay_order_takes_the_pow_path(env):
     chain = env.robots.lwr()
     w = env.synth.make_workload(chain, 256, 4, seed=8, io_dtype=np.float64)

@@ -2014,11 +2014,12 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     // wave per SIMD -- with eight waves resident per CU a 131 072-arm launch took 12.5 instead of 11.0 us (two waves
     // per SIMD compete for the same HBM time; profiles/r02_batch_scaling.txt).
     const size_t lds_lean = ((long)grid.x * (blk.x / 64) <= (long)a.n_simd) ? (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ) : lds;
-    bool lean = false;
+    bool lean = false, lean_any = false;  // lean: on the straight-line field path; lean_any: whatever the field path
     if constexpr (PL)
-        lean = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.ext && !a.q_ref && !a.q_cmded &&
+        lean_any = (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.null_control && !a.ext && !a.q_ref && !a.q_cmded &&
                !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.active && !a.q_lo &&
                !a.q_ref_out;
+    lean = lean_any && fastf;
     if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
         if (a.n_cycles > 0) {
             if constexpr (PL) {
@@ -2064,6 +2065,15 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
                 hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds_lean, stream, a);
                 return;
             }
+        }
+    }
+    if constexpr (PL) {
+        // the general field path (funnel / hemisphere / further attractors, mixed decay orders -- a goalAndNormal scene,
+        // object_feeder:248-303) with nothing but q -> qdot_out asked for: its own LEAN variant (the optional inputs and
+        // outputs as compile-time nulls free the registers the 14-joint kernel otherwise spills)
+        if (lean_any && !fastf && !a.q_out) {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, 1>), grid, blk, lds, stream, a);
+            return;
         }
     }
     if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 0>), grid, blk, lds, stream, a);
