@@ -6,11 +6,12 @@
 //   scripts/debug_jointlimits:61-73   distToCenter
 //   src/command_mixer.py:78-82        weighted sum of the command channels (+ bridge:188-195 limiter)
 //
-// Mapping (DESIGN.md "Kernel"): every arm is an independent ~2 kflop float64 problem whose largest
+// Mapping: every arm is an independent ~2 kflop float64 problem whose largest
 // matrix is 6 x n (n <= 16); a wavefront evaluates 64 arms, one per lane, entirely in registers,
-// with the chain constants as scalar (SGPR) operands from the kernarg block.  No cross-lane traffic
-// is needed, no lane idles, and the per-arm field list is read as a structure of arrays so every
-// wave-level load is one contiguous 256/512-byte row.  No MFMA: there is no contraction to feed it.
+// with every input of the cycle staged into the wave's LDS region by direct global -> LDS loads.  No
+// cross-lane traffic is needed, no lane idles, and the per-arm field list is read as a structure of
+// arrays so every wave-level load is one contiguous 1-KiB row.  No MFMA: there is no contraction to feed it.
+// Small lean batches (<= 4 096 arms) take cycle_sub8_kernel instead: eight lanes per arm (measured crossover).
 //
 // Arithmetic is float64 whatever the io dtype (DESIGN.md "Precision").
 #include "vfik_kernel.h"
