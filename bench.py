@@ -144,6 +144,17 @@ def c_oracle_rate(chain, params, w, threads, budget_s=8.0):
             "sample": "%d passes over the %d-arm batch in %.1f s, C oracle (oracle/vfik_oracle.c), OpenMP" % (passes, B, dt)}
 
 
+def kernel_name(io_name, n, flags, batch, sub8):
+    """The kernel a lean bench launch takes (vfik_kernel.hip, launch_v) -- as rocprofv3 names it, without spaces.
+    <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN, compile-time flags>: the bench
+    workloads are revolute chains with identity tool, unit weights, integer-order repellers and qdot_out only."""
+    t = "float" if io_name == "float32" else "double"
+    if sub8:
+        return "vfik::cycle_sub8_kernel<%s,%d>" % (t, n)
+    cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
+    return "vfik::cycle_kernel<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
+
+
 def pctl(xs, p):
     xs = sorted(xs)
     if len(xs) == 1:
@@ -402,8 +413,7 @@ def worker(args):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN>: the bench
                          # workloads (revolute chain, identity tool, unit weights, integer-order repellers, qdot_out only)
-                         "kernel": "vfik::cycle_kernel<%s,%d,%s,true,false,true,1>" % ("float" if io_name == "float32" else "double", chain.n,
-                                                                                "true" if flags & 1 else "false"),
+                         "kernel": kernel_name(io_name, chain.n, flags, B, eng.small_batch_launches > 0),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle,
                          "us_per_launch_hip_events": us_med,
                          "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),
