@@ -109,4 +109,22 @@ def test_random_configuration(env, seed):
     eng.reset_state()
     alone = eng.step_host(q, null_control=ctrl, want=("qdot_out",))
     assert np.abs(alone["qdot_out"].astype(np.float64) - ref["qdot_out"]).max() < tol, (seed, "qdot_out alone")
+    if seed % 3 == 0:
+        # ABI 3 on this configuration: a fresh-q gate and this cycle's own joint limits per arm (vf:312-313, nullspace:167)
+        eng.reset_state()
+        active = rng.random(B) < 0.7
+        half = 0.5 * (chain.q_hi - chain.q_lo) * rng.uniform(0.5, 1.0, (B, n))
+        mid = 0.5 * (chain.q_hi + chain.q_lo) + rng.uniform(-0.1, 0.1, (B, n))
+        lo, hi = (mid - half).astype(dt).astype(np.float64), (mid + half).astype(dt).astype(np.float64)
+        into_g = {k: (np.full(B, -7, dtype=np.int32) if k == "status" else np.full(got[k].shape, 3.25, dtype=dt)) for k in want}
+        into_r = {k: (np.full(B, -7, dtype=np.int32) if k == "status" else np.full(got[k].shape, 3.25)) for k in want}
+        g2 = eng.step_host(q, null_control=ctrl, want=want, active=active, q_lo=lo, q_hi=hi, into=into_g)
+        r2 = env["oc"].cycle_batch(chain, params, q, F, nf, tool=tool, null_control=ctrl, ext_cmd=ext, active=active, q_lo=lo, q_hi=hi,
+                                   into=into_r)
+        for k in want:
+            if k == "status":
+                assert np.array_equal(g2[k], r2[k]), (seed, "gated status")
+            else:
+                assert np.abs(g2[k].astype(np.float64) - r2[k]).max() < tol, (seed, "gated", k)
+        assert np.all(g2["qdot_out"][~active] == 3.25)
     eng.close()
