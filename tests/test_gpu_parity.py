@@ -180,6 +180,21 @@ def test_c4_one_shard_of_the_524288_arm_batch(env, rank):
     _compare(got, ref, TOL32, ("qdot_out", "status"))
 
 
+def test_c4_whole_batch_on_one_gpu(env):
+    """All 524 288 arms of C4 in ONE handle on one GPU (eight times the one-wave-per-SIMD batch: the launch runs in
+    rounds; index arithmetic beyond 2^19 arms x 24 quad planes), every arm against the oracle.  The eight shards are
+    what the eight ranks of `bench.py --gpus 8` hold (their seeds), concatenated."""
+    chain = env.robots.lwr()
+    parts = [env.synth.make_workload(chain, 65536, 8, seed=1 + r, io_dtype=np.float32) for r in range(8)]
+    w = {k: np.concatenate([p[k] for p in parts]) for k in ("q", "fields", "nfields")}
+    params = env.abi.default_params()
+    got, ref = _run_both(env, chain, params, w, np.float32, want=("qdot_out", "status"), max_slots=8)
+    _compare(got, ref, TOL32, ("qdot_out", "status"))
+    # a shard computed on its own gives the same rows (no arm sees another: SURVEY 8e)
+    g5, _ = _run_both(env, chain, params, parts[5], np.float32, want=("qdot_out",), max_slots=8)
+    assert np.array_equal(g5["qdot_out"], got["qdot_out"][5 * 65536:6 * 65536])
+
+
 @pytest.mark.parametrize("name,nobs", [("powercube6", 3), ("lwr", 2)])
 def test_other_joint_counts(env, name, nobs):
     chain = env.robots.by_name(name)
