@@ -469,11 +469,13 @@ __device__ __forceinline__ int q_lds_off(int b, int lane) {
 typedef __attribute__((address_space(1))) const void* GPtr;
 typedef __attribute__((address_space(3))) void* LPtr;
 
-// one quad plane: this lane's quad (QBYTES at gsrc) -> the Q16 1-KiB rows at byte offset `off` of the region
-template <typename T>
+// one quad plane: this lane's quad (QBYTES at gsrc) -> the Q16 1-KiB rows at byte offset `off` of the region.
+// NT: non-temporal cache policy (aux = 2) for bytes that one wave reads once per launch -- adopted for the long chains,
+// whose launches move 37 MB: C5 11.14 -> 10.68 us (-4.2 %, same-box A/B); C3 and C3N +-0.6 %, so they keep the default.
+template <typename T, bool NT = false>
 __device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int off) {
-    __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + off), 16, 0, 0);
-    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + off + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + off), 16, 0, NT ? 2 : 0);
+    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + off + 1024), 16, 0, NT ? 2 : 0);
 }
 
 template <typename T>
@@ -567,6 +569,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int arm = blockIdx.x * a.block + threadIdx.x;
     const long Bs = a.B;
     constexpr bool TABSC = NJ <= 8;  // sin / cos through the LDS table (sincos_tab_n)
+    constexpr bool NTL = NJ >= 10;   // non-temporal policy for the per-arm input planes (stage_quad)
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
     const KcPtr kc_launch = (KcPtr)(unsigned long long)a.kc;
@@ -601,12 +604,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stage_quad<T>(tg + k * planeB, region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP);
+        for (int k = 0; k < 3; ++k) stage_quad<T, NTL>(tg + k * planeB, region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP);
     }
     if (a.mixw) {  // per-arm mixer weights ([2][Bpad] quads: w0..w3 | w4 w5 - -); else KConst::mix_w
         const char* mg = static_cast<const char*>(a.mixw) + (long)arm * QB;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) stage_quad<T>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
+        for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
     {
         const char* qg = static_cast<const char*>(a.q) + (long)arm * NJ * sizeof(T);
@@ -632,7 +635,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // quads past the slots in use re-request plane 0 (cache hit) and are masked below, so the
         // number of outstanding requests is a compile-time constant for the counted waits
         const bool in = FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre;
-        stage_quad<T>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::slot_off(idx, NJ));
+        stage_quad<T, NTL>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::slot_off(idx, NJ));
     };
     constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
     // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     constexpr int EARLY_Q = NJ >= 10 ? 0 : 6;
     constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage_quad<T>(gg + k * planeB, region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
+    for (int k = 0; k < 4; ++k) stage_quad<T, NTL>(gg + k * planeB, region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
@@ -1054,7 +1057,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < QPC; ++idx) {
                         const int m = c0 + PRE + 2 * (idx / 3);  // first slot of the quad's pair
                         const char* sm = sg + (m < a.slots_used ? (long)((c0 + PRE) / 2 * 3 + idx) * planeB : 0);
-                        stage_quad<T>(sm, region, Stage<T>::slot_off(idx, NJ));
+                        stage_quad<T, NTL>(sm, region, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 double di[PRE], rb[PRE], rp[PRE];
@@ -1108,7 +1111,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < 2 * PRE; ++idx) {
                         const int m = c0 + (idx >> 1);
                         const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-                        stage_quad<T>(sm, region, Stage<T>::slot_off(idx, NJ));
+                        stage_quad<T, NTL>(sm, region, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 VFIK_WAIT_VM(0);
