@@ -128,3 +128,61 @@ def test_random_configuration(env, seed):
                 assert np.abs(g2[k].astype(np.float64) - r2[k]).max() < tol, (seed, "gated", k)
         assert np.all(g2["qdot_out"][~active] == 3.25)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_session(env, seed):
+    """A control session instead of a single cycle: 12 cycles on one handle with a random fresh-q gate every cycle, /control
+    messages, field sets of random arm ranges replaced between cycles (switching the batch between the straight-line and the
+    general field path and back), a speed-scale change -- against the oracle carrying its own per-arm state."""
+    abi = env["abi"]
+    rng = np.random.default_rng(5000 + seed)
+    robot = ["lwr", "lwr_dual14", "powercube6"][seed % 3]
+    chain = env["robots"].by_name(robot)
+    n = chain.n
+    B = [65, 200, 700][seed % 3]
+    dt = np.float32 if seed % 2 else np.float64
+    tol = 1e-9 if dt == np.float64 else 2e-5
+    flags = [abi.F_NULLSPACE | abi.F_MIXER, abi.F_NULLSPACE | abi.F_JOINT_LIMIT_TASK | abi.F_MIXER, 0][seed % 3]
+    params = abi.default_params(flags=flags)
+    F, nf = _random_fields(abi, chain, B, rng, dt, general=False)
+    M = F.shape[1]
+    eng = env["engine"].Engine(chain, B, io_dtype=dt, max_slots=3 * M, params=params)
+    eng.set_fields(F, nf)
+    states = env["oc"].new_states(B, n)
+    q = rng.uniform(0.8 * chain.q_lo, 0.8 * chain.q_hi, (B, n)).astype(dt).astype(np.float64)
+    want = ("qdot_vf", "qdot_null", "qdot_out", "status")
+    got = ref = None
+    for t in range(12):
+        if t in (3, 7, 9):  # new field sets for a random range of arms: general types at t = 3, repellers again at 7, 9
+            lo = int(rng.integers(0, B - 1))
+            hi = int(rng.integers(lo + 1, B + 1))
+            Fn, nn = _random_fields(abi, chain, hi - lo, rng, dt, general=(t == 3))
+            Fw = np.zeros((hi - lo, M), dtype=abi.FIELD_DTYPE)
+            k = min(M, Fn.shape[1])
+            Fw[:, :k] = Fn[:, :k]
+            nw = np.minimum(nn, k).astype(np.int32)
+            if t == 9:  # everything back to one decay order: the straight-line path again
+                lo, hi = 0, B
+                Fw, nw = np.zeros((B, M), dtype=abi.FIELD_DTYPE), np.zeros(B, dtype=np.int32)
+                Fa, na = _random_fields(abi, chain, B, rng, dt, general=False)
+                k = min(M, Fa.shape[1])
+                Fw[:, :k] = Fa[:, :k]
+                nw = np.minimum(na, k).astype(np.int32)
+            eng.set_fields(Fw, nw, first_arm=lo)
+            F[lo:hi], nf[lo:hi] = Fw, nw
+        if t == 5:
+            params.speed_scale = 0.3
+            eng.set_params(speed_scale=0.3)
+        active = rng.random(B) < 0.75 if t else np.ones(B, dtype=bool)
+        ctrl = rng.uniform(-1, 1, (B, 4)).astype(dt).astype(np.float64) if (flags & abi.F_NULLSPACE and n == 7) else None
+        got = eng.step_host(q, null_control=ctrl, want=want, active=active, into=got)
+        ref = env["oc"].cycle_batch(chain, params, q, F, nf, null_control=ctrl, states=states, active=active, into=ref, want=want)
+        ref.pop("states")
+        for k in want:
+            if k == "status":
+                assert np.array_equal(got[k], ref[k]), (seed, t, "status")
+            else:
+                assert np.abs(got[k].astype(np.float64) - ref[k]).max() < tol, (seed, t, k)
+        q = np.clip(q + 0.01 * ref["qdot_out"] + rng.normal(0, 0.01, q.shape), 0.95 * chain.q_lo, 0.95 * chain.q_hi).astype(dt).astype(np.float64)
+    eng.close()
