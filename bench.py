@@ -36,15 +36,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# What vf / nullspace / debug_jointlimits publish every cycle besides the mixed command (vf:341-342,462-466;
+# nullspace:180-184; debug_jointlimits:69-73), in scalars per arm: pose 16, pose_no_tool 16, qdotOut n, qdotout n, qdist n, status 1
+FULL_OUTS = ("pose", "pose_nt", "qdot_vf", "qdot_null", "qdist", "status")
+
 WORKLOADS = {
-    # name: (robot, batch per GPU, obstacles, io dtype, flags, algorithmic bytes per cycle [SURVEY 8d])
-    "C2": ("lwr", 4096, 4, "float64", 0, 512),
-    "C3": ("lwr", 65536, 8, "float32", 0, 384),
-    "C5": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 696),
+    # name: (robot, batch per GPU, obstacles, io dtype, flags, algorithmic bytes per cycle [SURVEY 8d], extra outputs)
+    "C2": ("lwr", 4096, 4, "float64", 0, 512, ()),
+    "C3": ("lwr", 65536, 8, "float32", 0, 384, ()),
+    "C5": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 696, ()),
     # C3 with the nullspace module and the mixer on, as `vfclik` starts them by default (vfclik:72-79); not a BASELINE config
-    "C3N": ("lwr", 65536, 8, "float32", 1 | 4, 384),
-    "C3D": ("lwr", 65536, 8, "float64", 0, 768),  # C3 with float64 I/O (not a BASELINE config)
+    "C3N": ("lwr", 65536, 8, "float32", 1 | 4, 384, ()),
+    "C3D": ("lwr", 65536, 8, "float64", 0, 768, ()),  # C3 with float64 I/O (not a BASELINE config)
+    # the reference-faithful cycle: C3N / C5 publishing everything the per-arm processes publish (SURVEY 8d "optional outputs":
+    # + (16 + 16 + 3 n + 1) scalars): 384 + 54 x 4 = 600 B, 696 + 75 x 4 = 996 B
+    "C3F": ("lwr", 65536, 8, "float32", 1 | 4, 600, FULL_OUTS),
+    "C5F": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 996, FULL_OUTS),
 }
+
+MIB = 1 << 20
 
 
 def host_cores(cap=16):
@@ -144,13 +154,15 @@ def c_oracle_rate(chain, params, w, threads, budget_s=8.0):
             "sample": "%d passes over the %d-arm batch in %.1f s, C oracle (oracle/vfik_oracle.c), OpenMP" % (passes, B, dt)}
 
 
-def kernel_name(io_name, n, flags, batch, sub8):
+def kernel_name(io_name, n, flags, batch, sub8, full=False):
     """The kernel a lean bench launch takes (vfik_kernel.hip, launch_v) -- as rocprofv3 names it, without spaces.
     <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN, compile-time flags>: the bench
     workloads are revolute chains with identity tool, unit weights, integer-order repellers and qdot_out only."""
     t = "float" if io_name == "float32" else "double"
     if sub8:
         return "vfik::cycle_sub8_kernel<%s,%d>" % (t, n)
+    if full:  # optional outputs asked for: the variant with run-time options
+        return "vfik::cycle_kernel<%s,%d,%s,true,false,true,0,-1>" % (t, n, "true" if flags & 1 else "false")
     cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
     return "vfik::cycle_kernel<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
 
@@ -180,6 +192,13 @@ def parse_args(argv=None):
                     help="nccl (= RCCL) is the real thing; gloo + --single-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="collate qdot of all ranks with one RCCL all_gather after the timed region")
+    ap.add_argument("--rotate", type=int, default=-1,
+                    help="input sets of the COLD measurement: that many independent handles + q / qdot buffers launched round-robin, so that "
+                         "no byte survives in the 256 MiB Infinity Cache between two uses (-1 = as many as make the bytes touched between "
+                         "two uses of a set exceed 640 MiB, at least 24; 0 = skip)")
+    ap.add_argument("--state", default="both", choices=["both", "warm", "cold"],
+                    help="both: `value` and `roofline` from back-to-back launches of ONE input set (cache-resident), `roofline.cold` from the "
+                         "rotating sets; cold: every launch of the run rotates (what a rocprofv3 trace of the cold state needs); warm: no rotation")
     ap.add_argument("--dump-reps", default=None, help="diagnostic: write the per-repetition times (us per launch, HIP events) to this file")
     ap.add_argument("--sync-each", action="store_true",
                     help="diagnostic: synchronize after every launch (un-overlapped kernel durations for a rocprofv3 kernel trace); "
@@ -208,7 +227,7 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    robot, B, nobs, io_name, flags, bytes_per_cycle = WORKLOADS[args.workload]
+    robot, B, nobs, io_name, flags, bytes_per_cycle, extra_outs = WORKLOADS[args.workload]
     io_dtype = np.dtype(io_name)
     chain = robots.by_name(robot)
     params = _abi.default_params(flags=flags)
@@ -222,10 +241,16 @@ def worker(args):
         cpu["os_cpu_count"] = os.cpu_count()
         cpu["best_cpu"] = c_oracle_rate(chain, params, w, cores)
 
+    # each rank on its own cores, before the first GPU call (the HIP runtime's threads inherit the mask); printed on stderr
+    binding = None
+    if world > 1:
+        from vfclik_amd import launcher
+        binding = launcher.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
     import torch
     import torch.distributed as dist
 
-    from vfclik_amd import engine
+    from vfclik_amd import engine, sharding
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -239,16 +264,55 @@ def worker(args):
         else:
             dist.init_process_group("gloo")
 
-    eng = engine.Engine(chain, B, io_dtype=io_dtype.type, max_slots=nobs, device=local_rank, params=params)
-    eng.set_fields(w["fields"], w["nfields"])
     tdt = torch.float32 if io_dtype == np.float32 else torch.float64
     dev = torch.device("cuda", local_rank)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the timing reductions run
-    q = torch.from_numpy(w["q"].astype(io_dtype)).to(dev)
-    qdot = torch.zeros(B, chain.n, dtype=tdt, device=dev)
     stream = torch.cuda.current_stream()
-    eng.use_stream(stream.cuda_stream)
-    io = eng.make_io(q, qdot_out=qdot)
+    out_cols = {"pose": 16, "pose_nt": 16, "qdot_vf": chain.n, "qdot_null": chain.n, "qdist": chain.n}
+
+    sharded = []
+
+    def make_set(shift):
+        """One independent input set: its own handle (field sets, nullspace state), q and output buffers.  Sets other than the
+        first hold the same workload with the arms rolled by `shift` rows: other bytes at other addresses."""
+        if shift == 0 and args.gather:
+            # the product's sharded driver: this rank's shard of the world * B arms on its device, local rows in
+            sharded.append(sharding.ShardedEngine(chain, world * B, rank=rank, world=world, devices=[local_rank],
+                                                  io_dtype=io_dtype.type, max_slots=nobs, params=params))
+            e = sharded[0].engines[0]
+        else:
+            e = engine.Engine(chain, B, io_dtype=io_dtype.type, max_slots=nobs, device=local_rank, params=params)
+        e.set_fields(np.roll(w["fields"], shift, axis=0), np.roll(w["nfields"], shift))
+        e.use_stream(stream.cuda_stream)
+        qt = torch.from_numpy(np.roll(w["q"], shift, axis=0).astype(io_dtype)).to(dev)
+        outs = {"qdot_out": torch.zeros(B, chain.n, dtype=tdt, device=dev)}
+        for k in extra_outs:
+            outs[k] = torch.zeros(B, dtype=torch.int32, device=dev) if k == "status" else torch.zeros(B, out_cols[k], dtype=tdt, device=dev)
+        return e, e.make_io(qt, **outs), qt, outs
+
+    eng, io, q, outs0 = make_set(0)
+    qdot = outs0["qdot_out"]
+    # bytes one launch really moves (PMC pass of an earlier run; the compact repeller image makes them fewer than the algorithmic ones)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get(args.workload, {})
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command, round %s; not measured by this run)" % rec.get("round")
+        except Exception:
+            traffic = None
+    # rotating input sets (the COLD state): enough of them that the bytes touched between two uses of a set exceed 640 MiB
+    per_launch = float(traffic) if traffic else float(bytes_per_cycle * B)
+    n_sets = 0
+    if args.state != "warm" and args.rotate != 0:
+        n_sets = args.rotate if args.rotate > 0 else max(24, int(640 * MIB / per_launch) + 2)
+    sets = [(eng, io)]
+    keep = [(q, outs0)]
+    for k in range(1, n_sets):
+        e_k, io_k, q_k, o_k = make_set(k * 2039)
+        sets.append((e_k, io_k))
+        keep.append((q_k, o_k))
 
     def barrier():
         if world > 1:
@@ -262,40 +326,53 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.cpu()]
 
-    for _ in range(args.warmup):
-        eng.step(io)
-    torch.cuda.synchronize()
-
-    # Repetitions alternate between two kinds: WALL repetitions (even) carry nothing but the K launches between the
-    # stamps and give `value`; EVENT repetitions (odd) bracket the same K launches with HIP events on the launch stream
-    # and give the kernel's launch period for `roofline`.  (Recording two timing events costs a 20-launch region
-    # ~20 us -- 1 us a step -- which is why they are kept out of the interval that `value` comes from.)
-    K, R = args.steps, args.reps
-    wall_s, ev_pairs, enqueue_s = [], [], []
-    for r in range(2 * R):
-        with_events = r % 2 == 1
-        if with_events:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()                      # ranks start together; the barrier itself is NOT inside the interval
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if with_events:
-            ev0.record(stream)
-        for _ in range(K):
-            eng.step(io)
+    def timed(active_sets, K, R, wall=True):
+        """R repetitions of the timed region; returns (wall seconds per WALL repetition, enqueue seconds, HIP-event ms per EVENT
+        repetition).  Repetitions alternate between two kinds: WALL repetitions (even) carry nothing but the K launches between
+        the stamps and give `value`; EVENT repetitions (odd) bracket the same K launches with HIP events on the launch stream
+        and give the kernel's launch period for `roofline`.  (Recording two timing events costs a 20-launch region ~20 us --
+        1 us a step -- which is why they are kept out of the interval that `value` comes from.)  Launch i of a repetition
+        goes to input set i mod len(active_sets): one set = back-to-back launches over the same bytes (cache-resident),
+        many = every launch finds its inputs in HBM."""
+        ns = len(active_sets)
+        steppers = [e_i.stepper(io_i) for e_i, io_i in active_sets]   # byref / prototype bound once: the hot enqueue
+        steps = [steppers[i % ns] for i in range(K)]
+        wall_s, ev_pairs, enqueue_s = [], [], []
+        for r in range(2 * R if wall else R):
+            with_events = (r % 2 == 1) or not wall
+            if with_events:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()                      # ranks start together; the barrier itself is NOT inside the interval
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if with_events:
+                ev0.record(stream)
             if args.sync_each:
-                torch.cuda.synchronize()
-        t_enq = time.perf_counter()
-        if with_events:
-            ev1.record(stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        if with_events:
-            ev_pairs.append((ev0, ev1))
-        else:
-            wall_s.append(t1 - t0)
-            enqueue_s.append(t_enq - t0)
-    ev_ms = [a.elapsed_time(b) for a, b in ev_pairs]  # same stream as the launches
+                for step in steps:
+                    step()
+                    torch.cuda.synchronize()
+            else:
+                for step in steps:
+                    step()
+            t_enq = time.perf_counter()
+            if with_events:
+                ev1.record(stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if with_events:
+                ev_pairs.append((ev0, ev1))
+            else:
+                wall_s.append(t1 - t0)
+                enqueue_s.append(t_enq - t0)
+        return wall_s, enqueue_s, [a.elapsed_time(b) for a, b in ev_pairs]  # events: same stream as the launches
+
+    K, R = args.steps, args.reps
+    primary = sets if args.state == "cold" else sets[:1]
+    for i in range(max(args.warmup, len(primary))):
+        e_i, io_i = primary[i % len(primary)]
+        e_i.step(io_i)
+    torch.cuda.synchronize()
+    wall_s, enqueue_s, ev_ms = timed(primary, K, R)
     own_wall_s = list(wall_s)
     wall_s = reduce_max(wall_s)        # per repetition: the slowest rank
     per_rank_ms = None
@@ -304,6 +381,23 @@ def worker(args):
         parts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         per_rank_ms = [float(p.item()) for p in parts]
+
+    # the COLD state beside the warm one (`--state both`): the same launches rotating over the input sets, HIP events only
+    cold = None
+    if args.state == "both" and n_sets > 1:
+        for e_i, io_i in sets:
+            e_i.step(io_i)
+        torch.cuda.synchronize()
+        _, _, cold_ms = timed(sets, K, R, wall=False)
+        cold_ms = reduce_max(cold_ms)
+        cold_us = [m * 1e3 / K for m in cold_ms]
+        cu = pctl(cold_us, 50)
+        cold = {"state": "cold: %d input sets (own handle, q and output buffers each) launched round-robin; %.0f MiB touched between two uses "
+                         "of a set, against 256 MiB of Infinity Cache" % (n_sets, (n_sets - 1) * per_launch / MIB),
+                "input_sets": n_sets, "us_per_launch": cu, "us_per_launch_p10": pctl(cold_us, 10), "us_per_launch_p90": pctl(cold_us, 90),
+                "achieved": bytes_per_cycle * B / (cu * 1e-6) / 1e9, "frac": bytes_per_cycle * B / (cu * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "real_bytes_frac": (traffic / (cu * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "cycles_per_s": world * B / (cu * 1e-6), "launches_timed": R * K}
 
     # secondary figure (never `value`): closed-loop rollout, K control cycles per launch with q integrated in
     # registers -- what the cycle costs once the per-launch boundary is amortised
@@ -360,9 +454,7 @@ def worker(args):
     if args.gather and world > 1:
         # optional collation of the per-rank results (NOT part of the control path): one all_gather
         src = qdot if args.dist_backend == "nccl" else qdot.cpu()
-        parts = [torch.empty_like(src) for _ in range(world)]
-        dist.all_gather(parts, src)
-        gathered = torch.cat(parts)
+        gathered = sharded[0].gather(src)   # sharding.collate: one all_gather over xGMI (RCCL), gloo in the rehearsal
 
     if rank == 0:
         got = qdot.cpu().numpy().astype(np.float64)
@@ -376,16 +468,13 @@ def worker(args):
             with open(args.dump_reps, "w") as f:
                 f.write("\n".join("%.4f %.4f" % (u, ws * 1e6 / K) for u, ws in zip(us_launch, wall_s)) + "\n")
         achieved = bytes_per_cycle * B / (us_med * 1e-6) / 1e9
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc)).get(args.workload, {})
-                traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command, round %s; not measured by this run)" % rec.get("round")
-            except Exception:
-                traffic = None
         total = world * B * K
+        if len(primary) > 1:
+            state_txt = ("cold: every launch of the run rotates over %d input sets (own handle, q and output buffers each), %.0f MiB touched "
+                         "between two uses of a set, against 256 MiB of Infinity Cache: inputs come from HBM" % (len(primary), (len(primary) - 1) * per_launch / MIB))
+        else:
+            state_txt = ("warm: back-to-back launches over ONE input set (%.1f MB), which stays in the 256 MiB Infinity Cache: this is "
+                         "the fraction of the HBM roofline at cache-resident inputs; `cold` = the same launches with inputs from HBM" % (per_launch / 1e6))
         line = {
             "metric": "7-DOF IK cycles/sec (whole node), batch=65536; max |qdot-qdot_ref|",
             "value": total / med_s,
@@ -411,9 +500,12 @@ def worker(args):
             "max_abs_err_rad_s": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         # which memory the launches of the timed region found their inputs in
+                         "state": state_txt,
+                         "real_bytes_frac": (traffic / (us_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN>: the bench
                          # workloads (revolute chain, identity tool, unit weights, integer-order repellers, qdot_out only)
-                         "kernel": kernel_name(io_name, chain.n, flags, B, eng.small_batch_launches > 0),
+                         "kernel": kernel_name(io_name, chain.n, flags, B, eng.small_batch_launches > 0, bool(extra_outs)),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle,
                          "us_per_launch_hip_events": us_med,
                          "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),
@@ -421,8 +513,13 @@ def worker(args):
         }
         if args.sync_each:
             line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"
+        if cold is not None:
+            line["roofline"]["cold"] = cold
+        if extra_outs:
+            line["config"]["outputs"] = ["qdot_out"] + list(extra_outs)
         if per_rank_ms is not None:
             line["per_rank_ms_per_step"] = per_rank_ms
+            line["config"]["rank0_cpu_binding"] = binding
         if rollout is not None:
             line["rollout"] = rollout
         if host_path is not None:
@@ -433,7 +530,8 @@ def worker(args):
             line["config"]["gathered_rows"] = int(gathered.shape[0])
         print(json.dumps(line), flush=True)
 
-    eng.close()
+    for e_k, _ in sets:
+        e_k.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -100,3 +100,74 @@ def test_percentiles():
     import bench
     xs = list(range(1, 12))
     assert bench.pctl(xs, 50) == 6 and bench.pctl(xs, 10) == 2 and bench.pctl(xs, 90) == 10 and bench.pctl([7.0], 90) == 7.0
+
+
+BIG_SCRIPT = textwrap.dedent("""
+    import os, sys, time
+    rank = int(os.environ["RANK"])
+    if rank == 0:
+        line = "x" * 1023
+        for i in range(512):          # 512 KiB: eight times what a pipe holds
+            print(line)
+        print("END-OF-RANK-0")
+    else:
+        time.sleep(0.5)
+""")
+
+
+def test_rank0_output_beyond_the_pipe_capacity_does_not_deadlock(tmp_path):
+    """rank 0's stdout is drained while the parent waits (RCCL logs at NCCL_DEBUG=INFO go to stdout)."""
+    from vfclik_amd import launcher
+    p = tmp_path / "big.py"
+    p.write_text(BIG_SCRIPT)
+    rc, out = launcher.spawn_ranks([sys.executable, str(p)], 2, timeout=60)
+    assert rc == 0
+    assert out.rstrip().endswith("END-OF-RANK-0") and len(out) > 512 * 1024
+
+
+def test_a_stuck_rank_times_out_and_everything_is_terminated(tmp_path):
+    from vfclik_amd import launcher
+    p = tmp_path / "stuck.py"
+    p.write_text("import os, time\nprint('hello from', os.environ['RANK'], flush=True)\ntime.sleep(300)\n")
+    import time
+    t0 = time.monotonic()
+    rc, out = launcher.spawn_ranks([sys.executable, str(p)], 2, timeout=2.0)
+    assert rc == 124 and "hello from 0" in out
+    assert time.monotonic() - t0 < 30
+    # main_spawn has a finite default and reports the timeout as its exit code
+    assert launcher.DEFAULT_SPAWN_TIMEOUT_S > 0
+    assert launcher.main_spawn(str(p), [], 2, timeout=1.5) == 124
+
+
+def test_rank_cpu_shares_are_disjoint_and_cover_every_rank():
+    from vfclik_amd import launcher
+    cpus = list(range(16, 48))
+    shares = [launcher.rank_cpus(r, 8, cpus) for r in range(8)]
+    assert all(len(s) == 4 for s in shares)
+    flat = [c for s in shares for c in s]
+    assert len(set(flat)) == len(flat) and set(flat) <= set(cpus)
+    assert launcher.rank_cpus(0, 2, list(range(64))) == list(range(8))          # capped at 8 per rank
+    assert launcher.rank_cpus(1, 2, list(range(64)), max_per_rank=0) == list(range(32, 64))
+    assert launcher.rank_cpus(5, 8, [3, 4]) == [4]                              # fewer CPUs than ranks: shared
+    with pytest.raises(ValueError):
+        launcher.rank_cpus(2, 2, cpus)
+
+
+def test_pin_rank_narrows_the_affinity_of_a_fresh_process(tmp_path):
+    """A rank pins itself before its first GPU call; done in a child so that the test runner keeps its own mask."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from vfclik_amd import launcher\n"
+            "before = sorted(os.sched_getaffinity(0))\n"
+            "mine = launcher.pin_rank(1, 2, log=sys.stdout)\n"
+            "after = sorted(os.sched_getaffinity(0))\n"
+            "assert mine == after and set(after) <= set(before), (mine, before, after)\n"
+            "assert len(before) < 2 or after != before\n"
+            "print('OK', after)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert "pinned to CPUs" in r.stdout and "OK" in r.stdout
+    env = dict(os.environ, VFIK_NO_PIN="1")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom vfclik_amd import launcher\nassert launcher.pin_rank(0, 2) is None" % ROOT],
+                       capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0, r.stderr

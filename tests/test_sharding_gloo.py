@@ -74,3 +74,91 @@ def test_shard_ranges_cover_the_batch():
             assert max(s) - min(s) <= 1 and sum(s) == batch
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+class _OracleEngine:
+    """Stand-in for engine.Engine in CPU tests of the sharding layer (the product has no CPU path): same
+    set_fields / step_host surface, computed by the oracle."""
+
+    def __init__(self, chain, batch, device=0, params=None, **kw):
+        from vfclik_amd import _abi
+        self.chain, self.batch, self.device = chain, batch, device
+        self.params = params if params is not None else _abi.default_params()
+
+    def set_fields(self, fields, counts, first_arm=0):
+        assert fields.shape[0] == self.batch and counts.shape[0] == self.batch
+        self.fields, self.counts = fields, counts
+
+    def step_host(self, q, null_control=None, want=("qdot_out",), **kw):
+        from oracle import oracle_c
+        assert q.shape[0] == self.batch
+        return oracle_c.cycle_batch(self.chain, self.params, q, self.fields, self.counts, null_control=null_control, want=tuple(want))
+
+    def close(self):
+        pass
+
+
+def _sharded_worker(rank, world, port, batch, devices, q):
+    import torch.distributed as dist
+    from vfclik_amd import robots, sharding, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    chain = robots.lwr()
+    w = synth.make_workload(chain, batch, 3, seed=11, io_dtype=np.float64)
+    sh = sharding.ShardedEngine(chain, batch, devices=devices, engine_factory=_OracleEngine)   # rank / world from the group
+    assert (sh.rank, sh.world) == (rank, world) and (sh.lo, sh.hi) == sharding.shard_range(batch, rank, world)
+    sh.set_fields(w["fields"], w["nfields"])                                                     # global arrays in
+    out = sh.step_global(w["q"], want=("qdot_out", "pose"))                                      # global rows out
+    # the rank-local form used by bench.py --gather: local field rows in, local rows out, one collate
+    sh2 = sharding.ShardedEngine(chain, batch, rank=rank, world=world, devices=[0], engine_factory=_OracleEngine)
+    sh2.set_fields(sh2.local(w["fields"]), sh2.local(w["nfields"]), global_rows=False)
+    loc = sh2.step_host(sh2.local(w["q"]), global_rows=False)
+    import torch
+    full2 = sh2.gather(torch.from_numpy(loc["qdot_out"])).numpy()
+    if rank == 0:
+        q.put((out["qdot_out"], out["pose"], full2, [(a, b) for a, b, _ in sh.parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch,devices", [(101, [0]), (64, [0, 1, 2]), (3, [0, 1, 2, 3])])
+def test_sharded_engine_global_batch_in_global_rows_out(batch, devices):
+    import torch.multiprocessing as mp
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots, synth
+    oracle_c.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, batch, devices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    qdot, pose, full2, parts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    chain = robots.lwr()
+    w = synth.make_workload(chain, batch, 3, seed=11, io_dtype=np.float64)
+    ref = oracle_c.cycle_batch(chain, _abi.default_params(), w["q"], w["fields"], w["nfields"], want=("qdot_out", "pose"))
+    assert np.array_equal(qdot, ref["qdot_out"]) and np.array_equal(pose, ref["pose"]) and np.array_equal(full2, ref["qdot_out"])
+    # rank 0's rows are split over its devices contiguously, empty parts dropped
+    assert parts[0][0] == 0 and all(parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
+    assert len(parts) == min(len(devices), (batch + 1) // 2)
+
+
+def test_sharded_engine_single_process_over_several_devices():
+    """world = 1: one process, one handle per device, the batch split over them (no torch.distributed needed)."""
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots, sharding, synth
+    oracle_c.build()
+    chain = robots.lwr()
+    w = synth.make_workload(chain, 37, 2, seed=5, io_dtype=np.float64)
+    sh = sharding.ShardedEngine(chain, 37, rank=0, world=1, devices=[0, 1, 2, 3], engine_factory=_OracleEngine)
+    assert [e.device for e in sh.engines] == [0, 1, 2, 3] and sum(e.batch for e in sh.engines) == 37
+    sh.set_fields(w["fields"], w["nfields"])
+    out = sh.step_global(w["q"])
+    ref = oracle_c.cycle_batch(chain, _abi.default_params(), w["q"], w["fields"], w["nfields"], want=("qdot_out",))
+    assert np.array_equal(out["qdot_out"], ref["qdot_out"])
+    with pytest.raises(ValueError):
+        sh.step_host(w["q"][:5])
+    sh.close()

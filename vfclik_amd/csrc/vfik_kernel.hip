@@ -508,6 +508,12 @@ template <typename T> struct SlotLds {
     }
 };
 
+// Chains of at least this many joints request their per-arm input planes with the non-temporal cache policy (stage_quad).
+// A build knob for the A/B of that policy in the warm (cache-resident) and the cold (HBM-sourced) state: tools/ab_compare.py --state.
+#ifndef VFIK_NT_MIN_NJ
+#define VFIK_NT_MIN_NJ 10
+#endif
+
 #define VFIK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // In-kernel section stamps for the diagnostic build only (make stamps; never in libvfik_hip.so).
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int arm = blockIdx.x * a.block + threadIdx.x;
     const long Bs = a.B;
     constexpr bool TABSC = NJ <= 8;  // sin / cos through the LDS table (sincos_tab_n)
-    constexpr bool NTL = NJ >= 10;   // non-temporal policy for the per-arm input planes (stage_quad)
+    constexpr bool NTL = NJ >= VFIK_NT_MIN_NJ;   // non-temporal policy for the per-arm input planes (stage_quad)
     // batch constants through the constant address space: always scalar loads
     typedef const KConst<NJ> __attribute__((address_space(4))) * KcPtr;
     const KcPtr kc_launch = (KcPtr)(unsigned long long)a.kc;

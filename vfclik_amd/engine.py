@@ -94,15 +94,12 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here = the library does not match include/vfik.h
         fn.restype = res
         fn.argtypes = args
-    # tools/ab_compare.py times an OLDER build against this one through bench.py: an ABI-2 library reads a prefix of
-    # the ABI-3 vfik_io and is never handed the new members there.  Nothing else may set this.
-    older_ok = os.environ.get("VFIK_AB_ALLOW_OLDER_ABI") == "1" and path != _abi.HIP_LIB_PATH
-    if lib.vfik_abi_version() != 3 and not (older_ok and lib.vfik_abi_version() == 2):
-        raise VfikError("ABI version mismatch")
+    if lib.vfik_abi_version() != _abi.ABI_VERSION:
+        raise VfikError("ABI version mismatch: library %d, binding %d" % (lib.vfik_abi_version(), _abi.ABI_VERSION))
     sizes = (C.c_size_t * 4)()
     lib.vfik_struct_sizes(sizes)
     mine = [C.sizeof(_abi.Field), C.sizeof(_abi.Chain), C.sizeof(_abi.Params), C.sizeof(IO)]
-    if list(sizes) != mine and not (older_ok and list(sizes)[:3] == mine[:3]):
+    if list(sizes) != mine:
         raise VfikError("struct layout mismatch: library %s, Python mirrors %s" % (list(sizes), mine))
     if path == _abi.HIP_LIB_PATH or _lib is None:
         _lib = lib
@@ -380,6 +377,20 @@ class Engine:
     def step(self, io):
         """Asynchronous launch on the handle's stream; ``io`` from :meth:`make_io`."""
         self._chk(self.lib.vfik_step(self.h, C.byref(io)))
+
+    def stepper(self, io):
+        """The hot enqueue as a zero-argument callable: ``byref(io)``, the handle and the prototype are bound ONCE, the
+        return code is checked inline.  ``io`` (and the buffers it names) must outlive the callable; changing a member of
+        ``io`` afterwards is seen by the next call (the library reads the struct at every launch).  What bench.py's timed loop and any
+        closed-loop driver at rate should call: at a 5-us launch period the Python-side cost of ``step`` is a third of the budget."""
+        fn, h, ref, err = self.lib.vfik_step, self.h, C.byref(io), self._chk
+
+        def step():
+            rc = fn(h, ref)
+            if rc:
+                err(rc)
+        step.io = io  # keeps the struct alive
+        return step
 
     def sync(self):
         self._chk(self.lib.vfik_sync(self.h))

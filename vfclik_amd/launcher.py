@@ -32,13 +32,55 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
+def allowed_cpus():
+    """The CPUs this process may run on (its cpuset), sorted."""
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except AttributeError:  # not Linux
+        return list(range(os.cpu_count() or 1))
+
+
+def rank_cpus(local_rank, local_world, cpus=None, max_per_rank=8):
+    """The slice of `cpus` (default: this process's cpuset) that rank `local_rank` of `local_world` pins itself to:
+    contiguous, disjoint, equal shares, at most `max_per_rank` CPUs each (the enqueue loop is one thread; HIP's helper
+    threads want a few more).  With fewer CPUs than ranks, several ranks share one CPU (round-robin)."""
+    cpus = allowed_cpus() if cpus is None else sorted(cpus)
+    if not cpus or local_world < 1 or not (0 <= local_rank < local_world):
+        raise ValueError("bad rank %d / world %d / cpus %r" % (local_rank, local_world, cpus))
+    per = len(cpus) // local_world
+    if per < 1:
+        return [cpus[local_rank % len(cpus)]]
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    return mine[:max_per_rank] if max_per_rank else mine
+
+
+def pin_rank(local_rank, local_world, log=None):
+    """Pin the calling process (a rank, BEFORE its first GPU call: the HIP runtime's threads inherit the mask) to its own
+    cores, so that eight 4-us enqueue loops on one host do not migrate over each other.  Prints the binding.
+    VFIK_NO_PIN=1 leaves the process where the launcher put it.  Returns the CPU list, or None when nothing was done."""
+    if os.environ.get("VFIK_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = rank_cpus(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:  # a cpuset we may not narrow: keep running unpinned
+        print("rank %d: sched_setaffinity(%s) failed: %s" % (local_rank, mine, e), file=sys.stderr, flush=True)
+        return None
+    print("rank %d of %d on this host: pinned to CPUs %s" % (local_rank, local_world, ",".join(map(str, mine))),
+          file=log or sys.stderr, flush=True)
+    return mine
+
+
 def spawn_ranks(argv, world, timeout=None, poll_s=0.05, env=None):
     """Run ``argv`` (a full command line, e.g. [sys.executable, "bench.py", ...]) as ``world`` ranks.
 
     Returns (returncode, rank0_stdout): returncode is 0 only if every rank exited 0; the first failing
     rank's code otherwise (the others are then terminated, as scripts/vfclik does with its process set),
-    or 124 on timeout.  Rank 0's stdout is captured and returned; the other ranks' stdout is discarded and
+    or 124 on timeout (every rank terminated).  Rank 0's stdout is drained CONTINUOUSLY by a reader thread
+    (a rank that prints more than a pipe holds -- RCCL at NCCL_DEBUG=INFO logs to stdout -- would otherwise
+    block in write() and stall its peers in the next collective); the other ranks' stdout is discarded and
     every rank's stderr passes through to ours."""
+    import threading
     if world < 1:
         raise ValueError("world must be >= 1")
     port = free_port()
@@ -46,11 +88,18 @@ def spawn_ranks(argv, world, timeout=None, poll_s=0.05, env=None):
     for r in range(world):
         procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port, env),
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    chunks = []
+
+    def drain(pipe):
+        for line in iter(pipe.readline, ""):
+            chunks.append(line)
+        pipe.close()
+
+    reader = threading.Thread(target=drain, args=(procs[0].stdout,), daemon=True)
+    reader.start()
     deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0
     try:
-        # rank 0's pipe is drained by communicate() below; poll the others first so that a crashed
-        # peer (which would leave rank 0 hanging in a collective) ends the run
         pending = set(range(world))
         while pending:
             for r in sorted(pending):
@@ -60,19 +109,13 @@ def spawn_ranks(argv, world, timeout=None, poll_s=0.05, env=None):
                 pending.discard(r)
                 if code != 0 and rc == 0:
                     rc = code
-            if rc != 0:
+            if rc != 0:  # a crashed peer would leave the others hanging in a collective: end the run
                 break
             if deadline is not None and time.monotonic() > deadline:
                 rc = 124
                 break
             if pending:
-                if 0 in pending:  # keep rank 0's pipe from filling up while we wait
-                    try:
-                        procs[0].wait(timeout=poll_s)
-                    except subprocess.TimeoutExpired:
-                        pass
-                else:
-                    time.sleep(poll_s)
+                time.sleep(poll_s)
     finally:
         if rc != 0:
             for p in procs:
@@ -83,14 +126,24 @@ def spawn_ranks(argv, world, timeout=None, poll_s=0.05, env=None):
                     p.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     p.kill()
-    out = procs[0].stdout.read() if procs[0].stdout else ""
-    return rc, out
+                    p.wait()
+    reader.join(timeout=10)
+    return rc, "".join(chunks)
 
 
-def main_spawn(script, args, world):
+DEFAULT_SPAWN_TIMEOUT_S = 1500.0
+
+
+def main_spawn(script, args, world, timeout=None):
     """Parent half of ``python script --gpus N`` without an external launcher: re-run the same command
-    line as N ranks and relay rank 0's stdout.  Returns the exit code."""
-    rc, out = spawn_ranks([sys.executable, script] + list(args), world)
+    line as N ranks and relay rank 0's stdout.  Returns the exit code.  A rank stuck in its rendezvous or in RCCL
+    initialisation must not hang the caller for ever: after ``timeout`` seconds (default VFIK_SPAWN_TIMEOUT or
+    1 500) every rank is terminated and the code is 124 -- fresh processes only, nothing is re-executed."""
+    if timeout is None:
+        timeout = float(os.environ.get("VFIK_SPAWN_TIMEOUT", DEFAULT_SPAWN_TIMEOUT_S))
+    rc, out = spawn_ranks([sys.executable, script] + list(args), world, timeout=timeout if timeout > 0 else None)
     sys.stdout.write(out)
     sys.stdout.flush()
+    if rc == 124:
+        print("%s: the %d ranks did not finish within %.0f s; terminated" % (os.path.basename(script), world, timeout), file=sys.stderr)
     return rc

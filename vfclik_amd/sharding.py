@@ -35,3 +35,108 @@ def collate(local, batch, dist=None):
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def _rank_world(rank, world):
+    """(rank, world) of this process: explicit arguments, else an initialised torch.distributed group, else the
+    launcher's environment (RANK / WORLD_SIZE), else a single process."""
+    import os
+    if rank is not None and world is not None:
+        return int(rank), int(world)
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+class ShardedEngine:
+    """A global batch of arms over the GPUs of a node: the batched analogue of scripts/vfclik:88-105, which starts
+    one process set per arm.  Rank r of ``world`` (one process per GPU under torch.distributed / bench.py's own
+    launcher) owns the contiguous arms ``shard_range(batch, r, world)``; inside a rank the shard is split once more over
+    ``devices`` (default: the rank's LOCAL_RANK device when world > 1, every visible device in a single process), one
+    ``Engine`` handle and one stream per device, launched asynchronously one after the other.  Global arrays in, the
+    rank's rows out; ``gather`` collates the rows of all ranks (one all_gather, never on the control path).
+
+    engine_factory(chain, batch, device=..., **kw) builds a handle (default ``engine.Engine``; CPU tests inject a
+    stand-in -- the product has no CPU path)."""
+
+    def __init__(self, chain, batch, rank=None, world=None, devices=None, engine_factory=None, **engine_kw):
+        import os
+        self.chain = chain
+        self.batch = int(batch)
+        self.rank, self.world = _rank_world(rank, world)
+        self.lo, self.hi = shard_range(self.batch, self.rank, self.world)
+        if engine_factory is None:
+            from .engine import Engine as engine_factory
+        if devices is None:
+            if self.world > 1:
+                devices = [int(os.environ.get("LOCAL_RANK", self.rank))]
+            else:
+                from .engine import load_library
+                devices = list(range(max(1, load_library().vfik_device_count())))
+        self.devices = list(devices)
+        # the rank's rows over its devices: again contiguous, sizes differing by at most one; devices left without an
+        # arm (more devices than arms) get no handle
+        self.parts = []
+        for k, dev in enumerate(self.devices):
+            a, b = shard_range(self.hi - self.lo, k, len(self.devices))
+            if b > a:
+                self.parts.append((self.lo + a, self.lo + b, engine_factory(chain, b - a, device=dev, **engine_kw)))
+        self.engines = [e for _, _, e in self.parts]
+
+    @property
+    def local_rows(self):
+        return self.hi - self.lo
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.parts, self.engines = [], []
+
+    def local(self, arr):
+        """This rank's rows of a global (batch, ...) array."""
+        if arr.shape[0] != self.batch:
+            raise ValueError("expected a global array of %d rows, got %d" % (self.batch, arr.shape[0]))
+        return arr[self.lo:self.hi]
+
+    def _rows(self, arr, name, global_rows):
+        if arr is None:
+            return [None] * len(self.parts)
+        want = self.batch if global_rows else self.local_rows
+        if arr.shape[0] != want:
+            raise ValueError("%s: expected %d rows (%s), got %d" % (name, want, "global" if global_rows else "this rank's", arr.shape[0]))
+        off = 0 if global_rows else self.lo
+        return [arr[a - off:b - off] for a, b, _ in self.parts]
+
+    def set_fields(self, fields, counts, global_rows=True):
+        """Field sets of the whole batch (global_rows) or of this rank's rows only (a caller that never holds the
+        global arrays, e.g. bench.py's per-rank synthetic workload)."""
+        for (a, b, e), f, c in zip(self.parts, self._rows(fields, "fields", global_rows), self._rows(counts, "counts", global_rows)):
+            e.set_fields(f, c)
+
+    def step_host(self, q, null_control=None, want=("qdot_out",), global_rows=True, **kw):
+        """One control cycle of this rank's arms: host arrays in (global or local rows), this rank's rows out.
+        Per-arm keyword arrays of Engine.step_host (q_ref, q_cmded, active, q_lo, q_hi) are sliced the same way."""
+        import numpy as np
+        qs = self._rows(q, "q", global_rows)
+        ncs = self._rows(null_control, "null_control", global_rows)
+        kws = {k: self._rows(v, k, global_rows) for k, v in kw.items() if k != "into"}
+        outs = []
+        for i, (a, b, e) in enumerate(self.parts):
+            outs.append(e.step_host(qs[i], null_control=ncs[i], want=want, **{k: v[i] for k, v in kws.items()}))
+        return {k: np.concatenate([o[k] for o in outs], axis=0) for k in want}
+
+    def gather(self, local_rows, dist=None):
+        """The rows of every rank, in arm order, on every rank (torch tensor in, torch tensor out)."""
+        if self.world == 1:
+            return local_rows
+        return collate(local_rows, self.batch, dist)
+
+    def step_global(self, q, want=("qdot_out",), dist=None, **kw):
+        """step_host on this rank's rows of the global q, then the collated global rows of every output."""
+        import torch
+        out = self.step_host(q, want=want, **kw)
+        return {k: self.gather(torch.from_numpy(v), dist).numpy() for k, v in out.items()}
