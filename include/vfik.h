@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VFIK_ABI_VERSION 3
+#define VFIK_ABI_VERSION 4
 
 enum {
     VFIK_OK = 0,
@@ -159,6 +159,16 @@ typedef struct vfik_io {
     void* q_ref_out;          /* out [B][n]   the joint controller's reference after its clamp: the reference KEEPS the clamped
                                  value (joint_p_controller:121 `ref = check_limits(ref, indata)`), so with limits that move
                                  a host feeds this back as the next cycle's q_ref.  Only with q_ref */
+    /* ---- ABI 4: the observers of the cycle, advanced by the SAME call on the cycle's own device results (no host round
+     * trip: the reference's vf computes its tracking error inside the loop body, vf:349-428, and monitor_distance reads
+     * the pose vf just published, monitor_distance:148-172).  vfik_step / vfik_step_host / vfik_submit_host only ---- */
+    void* track_error;        /* out [B][8]   the /track_error bottle (vf:418-427): vel_diff_angle, rot_diff_angle,
+                                 ext_vel_mag_corr, ext_rot_mag_corr, cmd_vel_mag_corr, cmd_rot_mag_corr, ext_int_diff,
+                                 arm_tracking; zeros until the 6th frame (vf:354).  Requesting it advances the handle's
+                                 per-arm history by one frame (gated arms: nothing, as in vfik_track_error) */
+    void* obj_dist;           /* out [B][n_objects][2]  xyz distance and rotation angle in DEGREES between the tool pose and
+                                 every object frame of vfik_set_objects -- the entries of /dmonitor/distOut
+                                 (monitor_distance:156-167).  Needs vfik_set_objects */
 } vfik_io;
 
 /* One control cycle for the whole batch -- the loop bodies of vf:311-466, nullspace:162-184,
@@ -217,6 +227,14 @@ int vfik_probe_field(vfik_handle* h, const void* pose, void* v6);
  * out[B][max_objects][2] = xyz distance, rotation angle in DEGREES -- one /dmonitor/distOut entry each
  * (monitor_distance:161-167).  Asynchronous on the handle's stream. */
 int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, int max_objects, void* out);
+
+/* The object frames of the distance monitor (scripts/monitor_distance keeps a dictionary id -> frame fed by
+ * /dmonitor/objectsIn, monitor_distance:72,111-129; object_feeder:215-227,306-315) as device state of the handle, rewritten
+ * only when a message changed them: host frames[n_arms][n_objects][16] doubles (row-major 4x4; unused slots: any finite
+ * frame, e.g. identity) for the arms [first_arm, first_arm + n_arms).  n_objects (1..4096) is one number for the batch; a
+ * call with another n_objects than the handle holds must cover every arm.  io->obj_dist of a cycle call then gets every
+ * arm's distances to its objects, computed on the device from the pose of that cycle. */
+int vfik_set_objects(vfik_handle* h, int first_arm, int n_arms, const double* frames, int n_objects);
 
 /* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
  * host weights[K], device out[B][n].  Bit-exact with the reference's left-to-right sum. */

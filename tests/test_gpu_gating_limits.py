@@ -305,6 +305,13 @@ def test_rollout_leaves_gated_arms_alone(env, robot):
     # (the gated launch is another kernel variant than the lean one: same arithmetic, another schedule -- not bit-equal)
     assert np.abs(got["q"][active] - full["q"][active]).max() < 1e-12
     assert np.abs(got["qdot_out"][active] - full["qdot_out"][active]).max() < 1e-10
-    assert np.all(got["q"][~active] == 0.0) and np.all(got["qdot_out"][~active] == 0.0)  # the zero-filled host rows came back
+    # a silent arm keeps its joint angles (the reference's arm keeps its state): q comes back as it went in, so that the result
+    # can be fed into the next rollout; the other outputs keep the caller's rows (zeros here, `into`'s rows below)
+    assert np.array_equal(got["q"][~active], w["q"][~active]) and np.all(got["qdot_out"][~active] == 0.0)
     assert np.abs(full["q"] - w["q"]).max() > 1e-3
+    # closed loop over two gated rollouts: the gated arms never move, the others advance; `into` keeps their last command
+    nxt = eng.rollout_host(got["q"], K, 2e-3, want=("qdot_out", "status"), active=active, into={"qdot_out": full["qdot_out"].copy()})
+    assert np.array_equal(nxt["q"][~active], w["q"][~active])
+    assert np.array_equal(nxt["qdot_out"][~active], full["qdot_out"][~active])
+    assert np.abs(nxt["q"][active] - got["q"][active]).max() > 1e-5
     eng.close()

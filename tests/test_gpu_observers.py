@@ -131,3 +131,67 @@ def test_field_probe_at_arbitrary_poses(dt, tol):
     assert np.abs(got).max() > 0.01
     eng.dev_free(d_pose); eng.dev_free(d_v6)
     eng.close()
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-9), (np.float32, 1e-3)])
+def test_observers_fused_into_the_cycle_call(dt, tol):
+    """ABI 4: io.track_error / io.obj_dist -- the tracking-error estimator and the distance monitor run in the SAME call
+    on the cycle's own device pose / twist (no host round trip, one synchronisation), with and without pose / v6 asked
+    for, under the fresh-q gate; against the NumPy restatements fed the published pose / twist."""
+    import __graft_entry__ as g
+    g.build()
+    from oracle import vfik_numpy as vn
+    from vfclik_amd import _abi, engine, robots, synth
+    chain = robots.lwr()
+    B, K, O, step = 192, 12, 3, 1.0 / 150.0
+    w = synth.make_workload(chain, B, 2, seed=43, io_dtype=dt)
+    params = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+    eng = engine.Engine(chain, B, io_dtype=dt, max_slots=4, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    with pytest.raises(engine.VfikError):   # the monitor needs its objects first
+        eng.step_host(w["q"], want=("qdot_out", "obj_dist"))
+    rng = np.random.default_rng(7)
+    frames = chain.fk(rng.uniform(chain.q_lo, chain.q_hi, (B * O, 7))).reshape(B, O, 16)
+    frames[:, 0] = w["fields"]["p"][:, 0, :16]          # object 0 = the goal (object_feeder:215-227)
+    eng.set_objects(frames)
+    est = [vn.TrackingError() for _ in range(B)]
+    q = w["q"].copy()
+    outs = None
+    seen = 0
+    for t in range(K):
+        active = rng.uniform(size=B) > 0.2 if t % 3 == 1 else None
+        ask_pose = t % 2 == 0                          # with and without the caller asking for pose / v6 itself
+        want = ("qdot_out", "track_error", "obj_dist", "goal_dist") + (("pose", "v6") if ask_pose else ())
+        if outs is not None:
+            outs = {k: v for k, v in outs.items() if k in want}
+        out = eng.step_host(q, want=want, active=active, into=outs)
+        ref_full = eng.step_host(q, want=("pose", "v6"))  # the same cycle's pose / twist (stateless outputs) for the restatement
+        outs = dict(out)
+        act = np.ones(B, dtype=bool) if active is None else active
+        for b in range(B):
+            if not act[b]:
+                continue
+            ref = est[b].update(vn.listToKdlFrame(ref_full["pose"][b].astype(np.float64)), ref_full["v6"][b, :3].astype(np.float64),
+                                ref_full["v6"][b, 3:].astype(np.float64))
+            if ref is None:
+                assert np.all(out["track_error"][b] == 0.0)
+            else:
+                seen += 1
+                assert np.abs(out["track_error"][b, :7] - ref[:7]).max() < (1e-7 if dt == np.float64 else 5e-6), (t, b, out["track_error"][b], ref)
+            if b % 13 == 0:
+                mon = vn.object_distances(ref_full["pose"][b].astype(np.float64), {k: frames[b, k].astype(dt).astype(np.float64) for k in range(O)})
+                for k, (oid, dxyz, dang) in enumerate(mon):
+                    assert abs(out["obj_dist"][b, k, 0] - dxyz) < (1e-9 if dt == np.float64 else 1e-5)
+                    assert abs(out["obj_dist"][b, k, 1] - dang) < (1e-6 if dt == np.float64 else 5e-2)
+                # object 0 is the goal: the monitor's entry equals the cycle kernel's own goal distance
+                assert abs(out["obj_dist"][b, 0, 0] - out["goal_dist"][b, 0]) < (1e-9 if dt == np.float64 else 1e-5)
+        q = q + step * np.where(act[:, None], out["qdot_out"].astype(np.float64), 0.0)
+    assert seen > B * (K - 6) * 0.7
+    # observers belong to single cycles
+    with pytest.raises(engine.VfikError):
+        eng.rollout_host(q, 3, 1e-3, want=("qdot_out", "track_error"))
+    # a partial update of the objects must keep n_objects
+    with pytest.raises(engine.VfikError):
+        eng.set_objects(frames[:5, :2], first_arm=0)
+    eng.set_objects(frames[5:9], first_arm=5)
+    eng.close()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Launch time and throughput of the lean C3 launch (7 joints, goal + 8 repellers, float32 I/O) over the batch size: what a
-second wave per SIMD is worth once the batch exceeds one wave per SIMD (65 536 arms = 1 024 waves)."""
+"""Launch time and throughput of the lean C3 launch (7 joints, goal + 8 repellers, float32 I/O) over the batch size, beyond
+one wave per SIMD (65 536 arms = 1 024 waves): the persistent launch (one wave per SIMD striding over the chunks, next chunk's
+inputs prefetched) against the launch in rounds (VFIK_PERSISTENT=0), same box, alternating.  `--flags 5` = the default process set."""
+import argparse
 import os
 import sys
 
@@ -12,17 +14,27 @@ import torch  # noqa: E402
 
 from vfclik_amd import _abi, engine, robots, synth  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--sizes", default="32768,65536,81920,98304,131072,196608,262144,393216,524288")
+a = ap.parse_args()
 chain = robots.lwr()
-for B in (16384, 32768, 65536, 81920, 98304, 131072, 196608, 262144, 524288):
+print("lean launch, 7 joints, goal + 8 repellers, float32 I/O, flags 0x%x; us per launch (median of 5 x 300 launches, HIP events)" % a.flags)
+print("%8s %6s %12s %12s %8s %14s %10s" % ("arms", "waves", "rounds us", "persistent", "ratio", "cycles/s", "of 8 TB/s"))
+for B in [int(x) for x in a.sizes.split(",")]:
     w = synth.make_workload(chain, B, 8, seed=3, io_dtype=np.float32)
-    eng = engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=_abi.default_params())
-    eng.set_small_batch_kernel(0)
-    eng.set_fields(w["fields"], w["nfields"])
-    q = torch.from_numpy(w["q"].astype(np.float32)).cuda()
-    out = torch.zeros(B, 7, dtype=torch.float32, device="cuda")
-    eng.use_stream(torch.cuda.current_stream().cuda_stream)
-    io = eng.make_io(q, qdot_out=out)
-    ts = [eng.time_steps(io, 30, 300) * 1e3 / 300 for _ in range(5)]
-    us = float(np.median(ts))
-    print("B %7d  waves %5d  %.3f us per launch  %.3e cycles/s  %.3f of the HBM roofline (384 B per cycle)" % (B, (B + 63) // 64, us, B / us * 1e6, 384 * B / us / 1e3 / 8000.0), flush=True)
-    eng.close()
+    res = {}
+    for pers in (0, 1):
+        os.environ["VFIK_PERSISTENT"] = str(pers)
+        eng = engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=_abi.default_params(flags=a.flags))
+        eng.set_small_batch_kernel(0)
+        eng.set_fields(w["fields"], w["nfields"])
+        q = torch.from_numpy(w["q"].astype(np.float32)).cuda()
+        out = torch.zeros(B, 7, dtype=torch.float32, device="cuda")
+        eng.use_stream(torch.cuda.current_stream().cuda_stream)
+        io = eng.make_io(q, qdot_out=out)
+        ts = [eng.time_steps(io, 30, 300) * 1e3 / 300 for _ in range(5)]
+        res[pers] = float(np.median(ts))
+        eng.close()
+    us = res[1]
+    print("%8d %6d %12.3f %12.3f %8.3f %14.3e %10.3f" % (B, (B + 63) // 64, res[0], res[1], res[1] / res[0], B / us * 1e6, 384 * B / us / 1e3 / 8000.0), flush=True)

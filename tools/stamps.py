@@ -18,7 +18,13 @@ COLD = "--cold" in sys.argv  # rotate over 34 input sets: the stamped launch fin
 robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr_dual14", 65536, 16, np.float32, 7),
                              "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5),
                              "C3G": ("lwr", 65536, 8, np.float32, 0), "GAN": ("lwr", 65536, 5, np.float32, 0),
-                             "C3D": ("lwr", 65536, 8, np.float64, 0)}[wl]
+                             "C3D": ("lwr", 65536, 8, np.float64, 0),
+                             # the full-output cycle (bench.py C3F / C5F): everything vf / nullspace / debug publish
+                             "C3F": ("lwr", 65536, 8, np.float32, 5), "C5F": ("lwr_dual14", 65536, 16, np.float32, 7),
+                             # ... and single extra outputs, to price them one by one
+                             "C3N+qdist": ("lwr", 65536, 8, np.float32, 5), "C3N+pose": ("lwr", 65536, 8, np.float32, 5)}[wl]
+EXTRA = {"C3F": ("pose", "pose_nt", "qdot_vf", "qdot_null", "qdist", "status"), "C5F": ("pose", "pose_nt", "qdot_vf", "qdot_null", "qdist", "status"),
+         "C3N+qdist": ("qdist",), "C3N+pose": ("pose",)}.get(wl, ())
 chain = robots.by_name(robot)
 w = synth.make_workload(chain, B, nobs, seed=1, io_dtype=io, max_fields=8 if wl == "GAN" else None)
 if wl == "GAN":  # goalAndNormal scene (object_feeder:248-303): attractor + funnel + near-goal repeller + 5 obstacles
@@ -40,7 +46,11 @@ def one_set():
     dq = e.dev_alloc(B * chain.n * np.dtype(io).itemsize)
     do = e.dev_alloc(B * chain.n * np.dtype(io).itemsize)
     e.h2d(dq, w["q"].astype(io))
-    return e, e.make_io(dq, qdot_out=do)
+    outs = {}
+    for k in EXTRA:
+        cols = {"pose": 16, "pose_nt": 16, "status": 1}.get(k, chain.n)
+        outs[k] = e.dev_alloc(B * cols * 4)
+    return e, e.make_io(dq, qdot_out=do, **outs)
 
 
 eng, ioo = one_set()

@@ -55,8 +55,14 @@ struct vfik_handle {
     // VFIK_SUB8_MAX_BATCH).  Measured crossover (tools/ab_mapping.py, float64 I/O, goal + 4 repellers): 3-7 % faster than
     // one lane per arm up to 4 096 arms, equal at 8 192, 1.4x / 2.0x / 2.8x SLOWER at 16 384 / 32 768 / 65 536.
     int sub8_max_batch = 4096;
+    int sub8_max_batch_full = 4096;  // the same for launches that publish more than qdot_out (set together by vfik_set_small_batch_kernel)
     long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
     int n_simd = 1024;       // 4 per CU of this device
+    // Batches beyond one wave per SIMD may take the persistent launch (cycle_kernel PERS; VFIK_PERSISTENT=1).  Off by default:
+    // same-box A/B, lean C3 launches, rounds vs persistent: 131 072 arms 10.37 / 10.71 us, 262 144 20.47 / 20.56, 524 288
+    // 41.3 / 39.5 -- the wave is bound by its float64 instruction issue, not by the waits the prefetch removes
+    // (profiles/r03_batch_scaling.txt).
+    int pers = 0;
     size_t esz = 4;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -79,6 +85,12 @@ struct vfik_handle {
     double* d_track = nullptr;  // tracking-error history [38][B], allocated on first use
     void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
+    // observers fused into the cycle call (ABI 4): object frames of the distance monitor [B][n_objects][16] in the io
+    // dtype, and the cycle's pose / field twist when the caller did not ask for them itself
+    void* d_objects = nullptr;
+    int n_objects = 0;
+    void* d_obs_pose = nullptr;
+    void* d_obs_v6 = nullptr;
     size_t dev_bytes = 0;
     // host bookkeeping
     std::vector<double> bridge_host;  // [B][8] mirror of d_mixw_arm: mixer weights 0..5, max_vel 6
@@ -88,9 +100,11 @@ struct vfik_handle {
     int fast_order = 0;
     int plain = 0;  // chain / tool / weights allow the PLAIN kernel variant
     bool speed_set = false;
-    // scratch for vfik_step_host
+    // vfik_step_host / vfik_rollout_host: one device arena + one pinned host arena for every member of the call
+    void* arena_dev = nullptr;
+    void* arena_host = nullptr;
+    size_t arena_bytes = 0;
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
-    Scratch sc[20];
     // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
     // its own device staging buffers and events; s_in / s_out are the side streams
     static constexpr int PIPE = 3;
@@ -227,7 +241,9 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q_hi = io->q_hi;
     a.q_ref_out = io->q_ref ? io->q_ref_out : nullptr;
     a.sub8_max_batch = h->sub8_max_batch;
+    a.sub8_max_batch_full = h->sub8_max_batch_full;
     a.n_simd = h->n_simd;
+    a.pers = h->pers;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -308,7 +324,8 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         int b = std::atoi(e);
         if (b == 64 || b == 128 || b == 192 || b == 256) h->block = b;  // tuning knob; LDS per block = waves x 27-56 KB
     }
-    if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = h->sub8_max_batch_full = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
@@ -352,9 +369,10 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_slots_fast, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1]};
+    void* ptrs[] = {h->d_goal, h->d_slots, h->d_slots_fast, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1], h->d_objects, h->d_obs_pose, h->d_obs_v6};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto& s : h->sc) if (s.p) (void)hipFree(s.p);
+    if (h->arena_dev) (void)hipFree(h->arena_dev);
+    if (h->arena_host) (void)hipHostFree(h->arena_host);
     for (auto& ps : h->pipe) {
         if (ps.ev_out) (void)hipEventSynchronize(ps.ev_out);
         for (auto& s : ps.sc) if (s.p) (void)hipFree(s.p);
@@ -682,6 +700,8 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     fill_kargs(h, io, a);
     a.dt = dt;
     a.clamp = clamp ? 1 : 0;
+    if (n_cycles > 0 && (io->track_error || io->obj_dist))
+        return fail(VFIK_E_ARG, "io->track_error / io->obj_dist are per control cycle: vfik_step only, not a rollout");
     if (n_cycles > 0 && h->n > VFIK_ROLL_MAX_NJ) {
         // Long chains: the rollout is n_cycles single-cycle launches, each integrating q on its way out
         // (q ping-pongs between two device buffers; the caller's io->q is never written).  The kernel has
@@ -710,10 +730,32 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     }
     a.n_cycles = n_cycles;
     a.q_out = q_out;
+    // observers of the cycle (ABI 4): they read the cycle's own pose / twist on the device
+    const bool want_track = io->track_error != nullptr, want_dist = io->obj_dist != nullptr;
+    if (want_track || want_dist) {
+        if (want_dist && (!h->d_objects || h->n_objects < 1)) return fail(VFIK_E_STATE, "io->obj_dist needs vfik_set_objects");
+        if (!a.pose) {
+            if (!h->d_obs_pose && dev_alloc(h, &h->d_obs_pose, (size_t)h->B * 16 * h->esz, true)) return VFIK_E_HIP;
+            a.pose = h->d_obs_pose;
+        }
+        if (want_track && !a.v6) {
+            if (!h->d_obs_v6 && dev_alloc(h, &h->d_obs_v6, (size_t)h->B * 6 * h->esz, true)) return VFIK_E_HIP;
+            a.v6 = h->d_obs_v6;
+        }
+        if (want_track && !h->d_track && dev_alloc(h, (void**)&h->d_track, (size_t)38 * h->B * sizeof(double), true)) return VFIK_E_HIP;
+    }
     int sub8 = 0;
     hipError_t e = vfik::launch_cycle(h->io_dtype, h->n, a, h->block, stream, &sub8);
     h->sub8_launches += sub8;
     if (e != hipSuccess) return fail(VFIK_E_HIP, "kernel launch: %s", hipGetErrorString(e));
+    if (want_track) {
+        e = vfik::launch_track(h->io_dtype, a.pose, a.v6, h->d_track, io->track_error, io->active, h->B, stream);
+        if (e != hipSuccess) return fail(VFIK_E_HIP, "track launch: %s", hipGetErrorString(e));
+    }
+    if (want_dist) {
+        e = vfik::launch_monitor(h->io_dtype, a.pose, h->d_objects, h->n_objects, (long)h->B * h->n_objects, io->obj_dist, stream);
+        if (e != hipSuccess) return fail(VFIK_E_HIP, "monitor launch: %s", hipGetErrorString(e));
+    }
     return VFIK_OK;
 }
 
@@ -734,7 +776,7 @@ int vfik_sync(vfik_handle* h) {
 
 // host-pointer forms: which vfik_io members are inputs / outputs, and their sizes in bytes
 namespace {
-constexpr int N_HIN = 7, N_HOUT = 11;
+constexpr int N_HIN = 7, N_HOUT = 13;
 struct HostIo {
     const void* hin[N_HIN];
     size_t bin[N_HIN];
@@ -746,8 +788,9 @@ HostIo host_io(const vfik_handle* h, const vfik_io* io, void* q_out_host) {
     HostIo x{{io->q, io->null_control, io->q_ref, io->q_cmded, io->active, io->q_lo, io->q_hi},
              {B * n * e, B * VFIK_NULL_CONTROLS * e, B * n * e, B * n * e, B * sizeof(int32_t), B * n * e, B * n * e},
              {io->qdot_vf, io->qdot_null, io->qdot_out, io->pose, io->pose_nt, io->v6, io->qdist, io->status, q_out_host, io->goal_dist,
-              io->q_ref ? io->q_ref_out : nullptr},
-             {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e, B * n * e}};
+              io->q_ref ? io->q_ref_out : nullptr, io->track_error, io->obj_dist},
+             {B * n * e, B * n * e, B * n * e, B * 16 * e, B * 16 * e, B * 6 * e, B * n * e, B * sizeof(int32_t), B * n * e, B * 2 * e, B * n * e,
+              B * 8 * e, B * (size_t)(h->n_objects > 0 ? h->n_objects : 1) * 2 * e}};
     return x;
 }
 void device_io(void* const* din, void* const* dout, vfik_io& d) {
@@ -756,45 +799,58 @@ void device_io(void* const* din, void* const* dout, vfik_io& d) {
     d.active = static_cast<const int32_t*>(din[4]); d.q_lo = din[5]; d.q_hi = din[6];
     d.qdot_vf = dout[0]; d.qdot_null = dout[1]; d.qdot_out = dout[2]; d.pose = dout[3]; d.pose_nt = dout[4];
     d.v6 = dout[5]; d.qdist = dout[6]; d.status = static_cast<int32_t*>(dout[7]); d.goal_dist = dout[9]; d.q_ref_out = dout[10];
+    d.track_error = dout[11]; d.obj_dist = dout[12];
 }
 }  // namespace
 
+// Host-pointer form: ONE copy in, the launches, ONE copy out, one synchronisation.  Inputs and outputs live in one device
+// arena and one pinned host arena (same layout, every member 256-byte aligned); the caller's arrays are packed into /
+// unpacked from the pinned arena on the host.  (Until round 3 every member was its own hipMemcpyAsync: with the eleven
+// outputs the port-level host layer asks for that was 197 us per call for ONE arm, ~15 us per copy, against 34 us for
+// qdot_out alone.)
 static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double dt, int clamp, void* q_out_host) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!io || !io->q) return fail(VFIK_E_ARG, "a control cycle needs io->q");
     HIP_TRY(hipSetDevice(h->device));
     const HostIo x = host_io(h, io, q_out_host);
-    auto need = [&](int i, size_t bytes) -> void* {
-        auto& s = h->sc[i];
-        if (s.bytes < bytes) {
-            if (s.p) (void)hipFree(s.p);
-            s.p = nullptr; s.bytes = 0;
-            if (hipMalloc(&s.p, bytes) != hipSuccess) return nullptr;
-            s.bytes = bytes;
-        }
-        return s.p;
-    };
-    void* din[N_HIN] = {};
-    for (int i = 0; i < N_HIN; ++i)
-        if (x.hin[i]) {
-            din[i] = need(i, x.bin[i]);
-            if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
-            HIP_TRY(hipMemcpyAsync(din[i], x.hin[i], x.bin[i], hipMemcpyHostToDevice, h->stream));
-        }
-    void* dout[N_HOUT];
-    for (int i = 0; i < N_HOUT; ++i) {
-        dout[i] = x.hout[i] ? need(N_HIN + i, x.bout[i]) : nullptr;
-        if (x.hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
-        // gated arms store nothing: their rows of the caller's arrays must come back as they went in
-        if (x.hout[i] && io->active) HIP_TRY(hipMemcpyAsync(dout[i], x.hout[i], x.bout[i], hipMemcpyHostToDevice, h->stream));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off_in[N_HIN], off_out[N_HOUT], total = 0;
+    for (int i = 0; i < N_HIN; ++i) { off_in[i] = total; if (x.hin[i]) total += up(x.bin[i]); }
+    const size_t in_bytes = total;
+    for (int i = 0; i < N_HOUT; ++i) { off_out[i] = total; if (x.hout[i]) total += up(x.bout[i]); }
+    if (h->arena_bytes < total) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->arena_dev) (void)hipFree(h->arena_dev);
+        if (h->arena_host) (void)hipHostFree(h->arena_host);
+        h->arena_dev = h->arena_host = nullptr;
+        h->arena_bytes = 0;
+        const size_t cap = total + total / 4 + 4096;
+        if (hipMalloc(&h->arena_dev, cap) != hipSuccess || hipHostMalloc(&h->arena_host, cap, hipHostMallocDefault) != hipSuccess)
+            return fail(VFIK_E_HIP, "arena allocation of %zu bytes failed", cap);
+        h->arena_bytes = cap;
     }
+    char* const hostA = static_cast<char*>(h->arena_host);
+    char* const devA = static_cast<char*>(h->arena_dev);
+    void* din[N_HIN] = {};
+    void* dout[N_HOUT] = {};
+    for (int i = 0; i < N_HIN; ++i)
+        if (x.hin[i]) { std::memcpy(hostA + off_in[i], x.hin[i], x.bin[i]); din[i] = devA + off_in[i]; }
+    size_t h2d = in_bytes;
+    for (int i = 0; i < N_HOUT; ++i)
+        if (x.hout[i]) {
+            dout[i] = devA + off_out[i];
+            // gated arms store nothing: their rows of the caller's arrays must come back as they went in
+            if (io->active) { std::memcpy(hostA + off_out[i], x.hout[i], x.bout[i]); h2d = total; }
+        }
+    HIP_TRY(hipMemcpyAsync(devA, hostA, h2d, hipMemcpyHostToDevice, h->stream));
     vfik_io d;
     device_io(din, dout, d);
     const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
-    for (int i = 0; i < N_HOUT; ++i)
-        if (x.hout[i]) HIP_TRY(hipMemcpyAsync(x.hout[i], dout[i], x.bout[i], hipMemcpyDeviceToHost, h->stream));
+    if (total > in_bytes) HIP_TRY(hipMemcpyAsync(hostA + in_bytes, devA + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < N_HOUT; ++i)
+        if (x.hout[i]) std::memcpy(x.hout[i], hostA + off_out[i], x.bout[i]);
     return VFIK_OK;
 }
 
@@ -966,6 +1022,32 @@ int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, 
     return VFIK_OK;
 }
 
+int vfik_set_objects(vfik_handle* h, int first_arm, int n_arms, const double* frames, int n_objects) {
+    if (check_handle(h)) return VFIK_E_ARG;
+    if (quiesce(h) != VFIK_OK) return VFIK_E_HIP;
+    if (!frames) return fail(VFIK_E_ARG, "null frames");
+    if (n_objects < 1 || n_objects > 4096) return fail(VFIK_E_ARG, "n_objects %d outside [1, 4096]", n_objects);
+    if (first_arm < 0 || n_arms < 1 || first_arm + n_arms > h->B) return fail(VFIK_E_ARG, "arm range [%d, %d) outside batch %d", first_arm, first_arm + n_arms, h->B);
+    if (n_objects != h->n_objects && (first_arm != 0 || n_arms != h->B))
+        return fail(VFIK_E_ARG, "n_objects changes from %d to %d: the call must cover every arm", h->n_objects, n_objects);
+    const size_t count = (size_t)n_arms * n_objects * 16;
+    for (size_t k = 0; k < count; ++k)
+        if (!std::isfinite(frames[k])) return fail(VFIK_E_ARG, "object frame entry %zu is not finite", k);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (n_objects != h->n_objects) {
+        if (h->d_objects) { (void)hipFree(h->d_objects); h->d_objects = nullptr; h->n_objects = 0; }
+        if (dev_alloc(h, &h->d_objects, (size_t)h->B * n_objects * 16 * h->esz, true)) return VFIK_E_HIP;
+        h->n_objects = n_objects;
+    }
+    std::vector<char> buf(count * h->esz);
+    for (size_t k = 0; k < count; ++k) { if (h->io_dtype == 32) put<float>(buf, k, frames[k]); else put<double>(buf, k, frames[k]); }
+    char* dst = static_cast<char*>(h->d_objects) + (size_t)first_arm * n_objects * 16 * h->esz;
+    HIP_TRY(hipMemcpyAsync(dst, buf.data(), buf.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VFIK_OK;
+}
+
 int vfik_mix(vfik_handle* h, const void* cmds, const double* weights, int K, void* out) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (!cmds || !weights || !out || K < 1 || K > 16) return fail(VFIK_E_ARG, "vfik_mix: bad arguments (K=%d)", K);
@@ -1047,6 +1129,7 @@ int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (max_batch < 0) return fail(VFIK_E_ARG, "max_batch must be >= 0");
     h->sub8_max_batch = max_batch;
+    h->sub8_max_batch_full = max_batch;
     return VFIK_OK;
 }
 

@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace vfik {
 namespace {
@@ -417,6 +418,189 @@ __device__ void eval_slot(const RD& rd, int m, const double* Rt, const double* p
 
 
 // ------------------------------------------------------------------------------------------------
+// Nullspace module, chains of up to 7 joints (scripts/nullspace:75-117), shared by cycle_kernel and cycle_sub8_kernel.
+// In: Jm = the Jacobian by columns (destroyed: its rows are orthonormalised in place), the arm's sign memory
+// (lv_r = lastvec, sig_r = sig, has_vec: lastvec holds a vector), c0 = /control[0], jl_task + descent(z) = the
+// joint-limit task's direction.  Out: qn = move_in_nullspace (+ the projected joint-limit task), before check_limits and
+// the gain; status bits; returns true when the sign memory was advanced (a unique nullspace direction exists).
+// Every decision is taken PER LANE (per arm): which path an arm takes never depends on the other arms of its wave, so
+// its result does not depend on where in a batch it sits (wave-wide votes only decide whether a path is executed at all).
+// ------------------------------------------------------------------------------------------------
+template <int NJ, typename ZF>
+__device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r, int& sig_r, bool& has_vec, double c0, bool jl_task,
+                                               ZF&& descent, double* qn, int& status) {
+    // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
+    // afterwards I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
+    // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
+    // Right-looking order: once row s is normalised, the projections of ALL later rows onto it are
+    // independent chains (5, 4, ... of them) that a lone wave can interleave; row by row (left-looking) the
+    // same operations are one serial chain of 7-term dot products (dependent float64 ops issue every ~8
+    // cycles, independent ones every ~5).  Same arithmetic, same order per row: same results.
+    int rank = 0;
+    double n0[6];  // squared norms of the rows of J: the rank test's yardstick
+#pragma unroll
+    for (int r = 0; r < 6; ++r) n0[r] = Jm[0][r] * Jm[0][r];
+#pragma unroll
+    for (int i = 1; i < NJ; ++i)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) n0[r] = __builtin_fma(Jm[i][r], Jm[i][r], n0[r]);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        double n1 = 0.0;
+        if (s == 0) {
+            n1 = n0[0];  // nothing has been projected out of the first row
+        } else {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) n1 += Jm[i][s] * Jm[i][s];
+        }
+        const bool keep = n1 > 1e-24 * n0[s] && n0[s] > 0.0;
+        double n1r, n1i;
+        sqrt_rsqrt(n1, n1r, n1i);
+        const double inv = keep ? n1i : 0.0;
+        rank += keep ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) Jm[i][s] *= inv;
+        double c[6];
+#pragma unroll
+        for (int r = s + 1; r < 6; ++r) c[r] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = s + 1; r < 6; ++r) c[r] += Jm[i][s] * Jm[i][r];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = s + 1; r < 6; ++r) Jm[i][r] -= c[r] * Jm[i][s];
+    }
+    const int nullity = NJ - rank;
+    bool advanced = false;
+    if (nullity == 1) {
+        double u[NJ];
+        // u <- (I - Q^T Q) u: all six coefficients first (independent dot products), then the update (classical
+        // Gram-Schmidt against an orthonormal Q); returns the largest |coefficient| = how much of u was row space
+        auto project = [&](double* x) {
+            double c[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) c[r] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * x[i];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) x[i] -= c[r] * Jm[i][r];
+            double cm = fabs(c[0]);
+#pragma unroll
+            for (int r = 1; r < 6; ++r) cm = fmax(cm, fabs(c[r]));
+            return cm;
+        };
+        auto norm2 = [&](const double* x) {
+            double n = 0.0;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) n += x[i] * x[i];
+            return n;
+        };
+        double nn = 0.0;
+        // Warm start: the nullspace direction turns little between two control cycles, so last cycle's vector
+        // (the sign memory, nullspace:92,104) is projected instead of a unit vector: no search for the best
+        // unit vector, and ONE projection suffices when it removes little (its residual row-space part is
+        // ~ eps cond(J) times what was removed).  An arm without a usable previous vector (first cycle, a
+        // jump that leaves less than half of it) takes the cold path below.
+        bool warm = false;
+        if (__any(has_vec)) {  // (a stored vector is a unit vector)
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) u[i] = lv_r[i];
+            const double cm = project(u);
+            nn = norm2(u);
+            warm = has_vec && nn > 0.25;
+            const bool again = warm && cm > 1e-2;  // a real move: project once more, as the cold path does
+            if (__any(again)) {
+                double u2[NJ];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) u2[i] = u[i];
+                project(u2);
+                const double nn2 = norm2(u2);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) u[i] = again ? u2[i] : u[i];
+                nn = again ? nn2 : nn;
+            }
+        }
+        if (__any(!warm)) {
+            // cold: the normalised column of the projector with the largest diagonal, projected twice
+            double dg[NJ], uc[NJ];
+            double best = -1.0;
+            int ib = 0;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) dg[i] = 1.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) dg[i] -= Jm[i][r] * Jm[i][r];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+                if (dg[i] > best) { best = dg[i]; ib = i; }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) uc[i] = (i == ib) ? 1.0 : 0.0;
+            project(uc);  // twice: the second pass squares the residual
+            project(uc);
+            const double nnc = norm2(uc);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) u[i] = warm ? u[i] : uc[i];
+            nn = warm ? nn : nnc;
+        }
+        double nrm, ninv;
+        sqrt_rsqrt(nn, nrm, ninv);
+        // All three sign decisions are taken on the un-normalised u and applied with the normalisation, in one
+        // multiplication per joint.  (1) The raw vector v as LAPACK's SVD leaves it: the first component that is
+        // not negligible (|v_i| > 1e-9 of the unit vector) is negative (oracle + golden).
+        const double thr = 1e-9 * nrm;
+        bool found = false, negate = false;  // negate: v = -u / |u|
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+            if (!found && fabs(u[i]) > thr) { found = true; negate = u[i] > 0.0; }
+        // (2) sign continuity against the previous cycle (nullspace:101-105): sig flips when sig v is farther from
+        // lastvec than -sig v; |sig v - l|^2 - |sig v + l|^2 = -4 sig (v . l), so only the sign of v . l counts
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) dot += u[i] * lv_r[i];
+        int sig = sig_r;
+        const double vl = negate ? -dot : dot;
+        if ((sig < 0 ? -vl : vl) < 0.0) sig = -sig;
+        sig_r = sig;
+        has_vec = true;
+        const double k = (negate != (sig < 0)) ? -ninv : ninv;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            u[i] *= k;
+            lv_r[i] = u[i];
+            qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
+        }
+        advanced = true;
+    } else if (nullity >= 2) {
+        status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
+    }
+    if (jl_task) {
+        double z[NJ];
+        descent(z);
+        double c[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) c[r] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * z[i];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) z[i] -= c[r] * Jm[i][r];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) qn[i] += z[i];
+    }
+    return advanced;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Staging through LDS (direct global -> LDS loads, no VGPR destination).  Every lane's inputs of
 // one cycle are requested at wave start and land in the wave's private LDS region while the
 // kinematics run; the arithmetic waits with counted s_waitcnt vmcnt at the three points where a
@@ -470,8 +654,11 @@ typedef __attribute__((address_space(1))) const void* GPtr;
 typedef __attribute__((address_space(3))) void* LPtr;
 
 // one quad plane: this lane's quad (QBYTES at gsrc) -> the Q16 1-KiB rows at byte offset `off` of the region.
-// NT: non-temporal cache policy (aux = 2) for bytes that one wave reads once per launch -- adopted for the long chains,
-// whose launches move 37 MB: C5 11.14 -> 10.68 us (-4.2 %, same-box A/B); C3 and C3N +-0.6 %, so they keep the default.
+// NT: non-temporal cache policy (aux = 2) for bytes that one wave reads once per launch.  Round 2 adopted it for the long
+// chains only (C5 -4.2 %; C3 and C3N +-0.6 %), from A/Bs in which back-to-back launches re-read one input set out of the
+// Infinity Cache.  With the inputs coming from HBM (rotating input sets, bench.py --state cold) it is worth -6.8 % on C3
+// (6.62 -> 6.16 us) and -5.8 % on C5, at +0.8 % / -4.3 % in the cache-resident state: every chain uses it since round 3
+// (profiles/r03_nt_ab.txt).
 template <typename T, bool NT = false>
 __device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int off) {
     __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + off), 16, 0, NT ? 2 : 0);
@@ -511,8 +698,9 @@ template <typename T> struct SlotLds {
 // Chains of at least this many joints request their per-arm input planes with the non-temporal cache policy (stage_quad).
 // A build knob for the A/B of that policy in the warm (cache-resident) and the cold (HBM-sourced) state: tools/ab_compare.py --state.
 #ifndef VFIK_NT_MIN_NJ
-#define VFIK_NT_MIN_NJ 10
+#define VFIK_NT_MIN_NJ 0
 #endif
+
 
 #define VFIK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -555,8 +743,15 @@ template <typename T> struct SlotLds {
 // CF = the feature flags as a compile-time constant, or -1: read from the launch.  The two flag sets the reference's
 // default process set produces with the nullspace module (vfclik:95-97: nullspace + mixer; C5 adds the joint-limit
 // task) get their own LEAN kernels, so that the branches of the other options are not in the code at all.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1>
+// PERS = persistent launch for batches beyond one wave per SIMD (lean straight-line launches, float I/O, chains of up to 7
+// joints): the grid is one wave per SIMD, every wave strides over the 64-arm chunks of the batch, and while it computes
+// chunk k the requests of chunk k + 1 -- q, goal block, slot quads -- are in flight into a SECOND per-arm area of its LDS
+// region (they are issued between the joints of the kinematics, where the first chunk's slot requests go).  Launched in
+// rounds of one wave per SIMD instead, 131 072 arms cost 2.33 x the 65 536-arm launch: every round pays its own request
+// phase, q round trip and tail.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) cycle_kernel(const KArgs a_in) {
+    static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7), "PERS: lean straight-line float launches only");
     KArgs a = a_in;
     if constexpr (CF >= 0) a.flags = (unsigned)CF;
     if constexpr (LEAN != 0) {  // 1: lean, 2: lean with q_out kept (one cycle of a stepped rollout, long chains)
@@ -572,7 +767,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
     asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots), "s"(a.slots_fast),
                  "s"(a.tool), "s"(a.mixw), "s"(a.kc));
-    const int arm = blockIdx.x * a.block + threadIdx.x;
+    // PERS: one wave per block; chunk = 64 consecutive arms; lanes past the end of the batch compute arm B - 1 again and store nothing
+    const int nchunks = (a.B + 63) >> 6;
+    int chunk = PERS ? (int)blockIdx.x : 0;
+    int arm = PERS ? chunk * 64 + (int)threadIdx.x : (int)(blockIdx.x * a.block + threadIdx.x);
     const long Bs = a.B;
     constexpr bool TABSC = NJ <= 8;  // sin / cos through the LDS table (sincos_tab_n)
     constexpr bool NTL = NJ >= VFIK_NT_MIN_NJ;   // non-temporal policy for the per-arm input planes (stage_quad)
@@ -589,6 +787,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // (LEAN launches run the straight-line path and touch only the head of the region: their waves are packed closer)
     constexpr int REGION_BYTES = (LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);
     char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * REGION_BYTES;
+    // per-arm inputs (goal block, first-chunk slot quads, q) of the chunk being computed: the head of the region, or
+    // (PERS, odd chunks of the wave) the second per-arm area behind the constants and the table
+    char* dreg = region;
+    constexpr int DAREA2 = Stage<T>::lean_bytes(NJ);      // offset of the second per-arm area; it is kin_off(NJ) bytes long
     const long Bp = a.Bpad;
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
     constexpr int PRE = Stage<T>::PRE;
@@ -602,10 +804,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // the sin / cos table (64 x 16 bytes) sits behind the constants, on the next 1-KiB boundary
         if constexpr (TABSC) __builtin_amdgcn_global_load_lds((GPtr)(kg + KTab<NJ>::OFFSET), (LPtr)(region + Stage<T>::tab_off(NJ)), 16, 0, 0);
     }
-    if (arm >= a.B) return;
+    if constexpr (!PERS) {
+        if (arm >= a.B) return;
+    }
     // Fresh-q gate (vf:312-313, nullspace:162-163): an arm whose joint angles did not arrive this cycle stores
     // nothing.  Requested first, consumed at the stores: every counted wait below covers this oldest request.
     int act = 1;
+    if constexpr (PERS) {
+        act = arm < a.B;
+        arm = arm < a.B ? arm : a.B - 1;
+    }
     if (a.active) act = a.active[arm];
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
         const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
@@ -617,51 +825,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
-    {
-        const char* qg = static_cast<const char*>(a.q) + (long)arm * NJ * sizeof(T);
-        char* qrow = region + Stage<T>::Q_OFF;
-        constexpr int n16 = Stage<T>::q16(NJ), rem = Stage<T>::qrem(NJ);
+    constexpr int NQREQ = Stage<T>::q16(NJ) + Stage<T>::qrem(NJ) / 4;   // requests that bring one q vector
+    auto issue_q_piece = [&](int r, int armx, char* dr) {  // piece r of arm armx's q into the per-arm area dr
+        const char* qg = static_cast<const char*>(a.q) + (long)armx * NJ * sizeof(T);
+        char* qrow = dr + Stage<T>::Q_OFF;
+        constexpr int n16 = Stage<T>::q16(NJ);
+        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
+    };
 #pragma unroll
-        for (int i = 0; i < n16; ++i) __builtin_amdgcn_global_load_lds((GPtr)(qg + i * 16), (LPtr)(qrow + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < rem / 4; ++j)
-            __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + j * 4), (LPtr)(qrow + n16 * 1024 + j * 256), 4, 0, 0);
-    }
+    for (int r = 0; r < NQREQ; ++r) issue_q_piece(r, arm, dreg);
     // The goal and slot requests are issued later, between the joints of the kinematics: a load costs
     // the issuing wave ~50 cycles while the CU's four waves queue on the one address unit
     // (tools/ubench_loads.hip), and spreading them out lets that queue drain under arithmetic.
     const int npre = a.slots_used < PRE ? a.slots_used : PRE;
-    const char* const gg = static_cast<const char*>(a.goal) + (long)arm * QB;
     // The straight-line path reads the COMPACT repeller image (two slots in three quads, vfik_kernel.h): a chunk of PRE
     // slots is QPC = 3 PRE / 2 quads instead of 2 PRE -- a quarter fewer bytes and requests for what is, at these
     // batches, the longest wait of the wave (the slots' data is the last to arrive).
     constexpr int QPC = FASTF ? 3 * PRE / 2 : 2 * PRE;       // slot quads per chunk
-    const char* const sg = static_cast<const char*>(FASTF ? a.slots_fast : a.slots) + (long)arm * QB;
-    auto issue_slot_quad = [&](int idx) {  // idx in [0, QPC): quad idx of the first chunk
+    const char* const goal0 = static_cast<const char*>(a.goal);
+    const char* const slots0 = static_cast<const char*>(FASTF ? a.slots_fast : a.slots);
+    const char* sg = slots0 + (long)arm * QB;  // this arm's quad of slot plane 0
+    auto issue_goal_quad = [&](int k, int armx, char* dr) {
+        stage_quad<T, NTL>(goal0 + (long)armx * QB + k * planeB, dr, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
+    };
+    auto issue_slot_quad_of = [&](int idx, int armx, char* dr) {  // idx in [0, QPC): quad idx of the first chunk of slots
         // quads past the slots in use re-request plane 0 (cache hit) and are masked below, so the
         // number of outstanding requests is a compile-time constant for the counted waits
         const bool in = FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre;
-        stage_quad<T, NTL>(sg + (in ? (long)idx * planeB : 0), region, Stage<T>::slot_off(idx, NJ));
+        stage_quad<T, NTL>(slots0 + (long)armx * QB + (in ? (long)idx * planeB : 0), dr, Stage<T>::slot_off(idx, NJ));
     };
+    auto issue_slot_quad = [&](int idx) { issue_slot_quad_of(idx, arm, dreg); };
     constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
     // The wave has to sit out q's round trip (~500 cycles) anyway: the goal block and the first EARLY_Q
     // slot quads are requested into that wait, the remaining slot quads between the joints.
     // (long chains have two rows of constants and five q pieces in front already: nothing early there, C5 -1.3 %)
-    constexpr int EARLY_Q = NJ >= 10 ? 0 : 6;
+    // PERS: the first chunk's requests all go out here; the slots between the joints are the NEXT chunk's requests.
+    constexpr int EARLY_Q = PERS ? QPC : (NJ >= 10 ? 0 : 6);
     constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
+    // PERS: request r of a chunk's NPF = q pieces, goal quads, slot quads, in that order (float I/O: one request a quad)
+    constexpr int NPF = PERS ? NQREQ + 4 + QPC : 0;
+    constexpr int PF_PER_JOINT = (NPF + NJ - 1) / NJ;
+    auto issue_prefetch = [&](int r, int armx, char* dr) {
+        if (r < NQREQ) issue_q_piece(r, armx, dr);
+        else if (r < NQREQ + 4) issue_goal_quad(r - NQREQ, armx, dr);
+        else issue_slot_quad_of(r - NQREQ - 4, armx, dr);
+    };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage_quad<T, NTL>(gg + k * planeB, region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
+    for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
-    VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal and early slot requests may still be out)
     const KConst<NJ>* const kl = reinterpret_cast<const KConst<NJ>*>(region + Stage<T>::kin_off(NJ));  // kinematics block only
-    STAMP(2);
-    {
-        const char* qrow = region + Stage<T>::Q_OFF;
+    bool has_next = false;    // PERS: this wave has another chunk of arms after the current one (wave-uniform)
+    int arm_next = 0;         // PERS: this lane's arm of that chunk (clamped to the batch)
+    char* dreg_next = region;
+    auto read_q = [&]() {
+        const char* qrow = dreg + Stage<T>::Q_OFF;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             if (Q16 == 1) {
@@ -672,6 +895,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 q[i] = __hiloint2double(hi, lo);
             }
         }
+    };
+    if constexpr (!PERS) {
+        VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal and early slot requests may still be out)
+        STAMP(2);
+        read_q();
     }
     // nullspace sign memory (nullspace:91-92) lives in registers across the cycles of a launch
     int sig_r = 1;
@@ -700,8 +928,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     };
     // The state is requested a phase ahead of its use (read where it is used, the round trip stood in the wave's
-    // way, ~1 500 cycles): a rollout loads it here, once; a single cycle requests it in front of the Gram-Schmidt
-    // block, which covers the latency without the registers being held through kinematics, field and IK.
+    // way, ~1 500 cycles): a rollout loads it here, once; a single cycle requests it behind the field evaluation, in
+    // front of the IK's solve, which covers the latency without the registers being held through kinematics and field.
     // Chains of 8+ joints have nullity >= 2 and never use the sign memory.
     auto load_null_state = [&]() {
         const f4s* sp = reinterpret_cast<const f4s*>(a.lastvec) + arm;
@@ -718,6 +946,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     };
     if constexpr (NULLSP && NJ <= 7 && ROLL) load_null_state();
     const int ncyc = ROLL ? a.n_cycles : 1;
+    for (;;) {  // PERS: the wave's chunks of arms; otherwise one pass
+    if constexpr (PERS) {
+        // Top of a chunk.  First chunk: constants, table and q have landed (goal and slots may still be out).  Later chunks:
+        // everything landed before the previous chunk's stores (the wait in front of them), and those few stores are
+        // younger than anything this wait looks at.
+        VFIK_WAIT_VM((4 + QPC) * Q16);
+        STAMP(2);
+        read_q();
+        status = 0;
+        const int nxt = chunk + (int)gridDim.x;
+        has_next = nxt < nchunks;
+        const int an = nxt * 64 + (int)threadIdx.x;
+        arm_next = an < a.B ? an : a.B - 1;
+        dreg_next = dreg == region ? region + DAREA2 : region;
+    }
     for (int cyc = 0; cyc < ncyc; ++cyc) {
     // The LDS addresses are made opaque once per cycle for long chains: otherwise the compiler hoists the
     // cycle-invariant reads (constants, goal, slots: ~200 doubles) out of the cycle loop and spills.
@@ -816,6 +1059,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
             if (first && EARLY_Q + i * SLOTQ_PER_JOINT + k < QPC) issue_slot_quad(EARLY_Q + i * SLOTQ_PER_JOINT + k);
+        if constexpr (PERS) {  // the next chunk's requests, into the other per-arm area, a few after every joint
+            if (has_next) {
+#pragma unroll
+                for (int k = 0; k < PF_PER_JOINT; ++k)
+                    if (i * PF_PER_JOINT + k < NPF) issue_prefetch(i * PF_PER_JOINT + k, arm_next, dreg_next);
+            }
+        }
     }
     if (!PLAIN) {   // trailing z-screw of the last fixed transform
         const double tc = klc->tail_c, ts = klc->tail_s, te = klc->tail_e;
@@ -914,29 +1164,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // the Jacobian lives in AGPRs and every further pass costs 168 register moves.)
     const double* wts = (!PLAIN && a.wts) ? a.wts + arm : nullptr;
     const long wpitch = a.Bpad;
-    double Sw[PLAIN ? 1 : NJ][6];
     double A[6][6], dinv[6];
     double G[FUSEP ? 6 : 1][6], wn[6];  // FUSEP: undamped Gram matrix and J z of the projector
-    double (*const S)[6] = PLAIN ? Jm : Sw;
+    // Weighted form (vf:295-309: Wy = diag of the 't' weights, Wq of the 'j' weights), without a weighted copy of the
+    // Jacobian: A = Wy (J Wq^2 J^T) Wy + lambda^2 I and qdot = Wq^2 J^T (Wy y).  (Until round 3 the general variants kept
+    // Sw = Wy J Wq beside J: 12 n more registers, which the 10- and 14-joint kernels and the rollouts spilled to scratch.)
+    double wyv[PLAIN ? 1 : 6];
+    auto wq2_of = [&](int i) {  // wq_i^2 of this arm
+        const double wqi = wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i];
+        return wqi * wqi;
+    };
     auto ik_factor = [&]() {
-        if (!PLAIN) {
-            if (wts) {  // wave-uniform: the arm's own weights, read where they are used
+        if constexpr (!PLAIN) {
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    const double wqi = wts[(long)(6 + i) * wpitch];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) Sw[PLAIN ? 0 : i][r] = wts[(long)r * wpitch] * Jm[i][r] * wqi;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        Sw[PLAIN ? 0 : i][r] = kc->wy[r] * Jm[i][r] * kc->wq[i];
-                        Sw[PLAIN ? 0 : i][3 + r] = kc->wy[3 + r] * Jm[i][3 + r] * kc->wq[i];
-                    }
-                }
-            }
+            for (int r = 0; r < 6; ++r) wyv[PLAIN ? 0 : r] = wts ? wts[(long)r * wpitch] : kc->wy[r];
         }
         constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
         if constexpr (ACCJ) {  // accumulated with the Jacobian columns above
@@ -951,7 +1192,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA) ? kc->lambda2 : 0.0;
+                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && PLAIN) ? kc->lambda2 : 0.0;
             if constexpr (FUSEP) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
@@ -961,11 +1202,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NJ; ++i)  // joint by joint: 21 independent accumulators per step
+            for (int i = 0; i < NJ; ++i) {  // joint by joint: 21 independent accumulators per step
+                double t[6];
+                if constexpr (!PLAIN) {
+                    const double w2 = wq2_of(i);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) t[r] = w2 * Jm[i][r];
+                }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(S[i][r], S[i][c], A[r][c]);
+                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(PLAIN ? Jm[i][r] : t[r], Jm[i][c], A[r][c]);
                     if constexpr (FUSEP) {
                         wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
                         if constexpr (!PLAIN) {
@@ -974,6 +1221,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                         }
                     }
                 }
+            }
+            if constexpr (!PLAIN) {  // A <- Wy A Wy + lambda^2 I
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(wyv[PLAIN ? 0 : r] * wyv[PLAIN ? 0 : c], A[r][c], r == c ? kc->lambda2 : 0.0);
+            }
         }
         if constexpr (GFROMA) {
 #pragma unroll
@@ -1008,11 +1262,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0};
     double gdist[2] = {0.0, 0.0};  // distance and rotation angle to the goal (monitor_distance:161-167)
     double speed;  // this arm's speedScale (vf:134-137,197-207), 4th component of the goal block's last quad
+    // (Round 3 tried pinning the factorisation in front of this wait by tying the wait to its results: neutral in the cold
+    // state, noisy-to-slower in the warm one; the compiler's own placement stays.)
+    if (PERS && has_next) VFIK_WAIT_VM(N_SLOT + NPF);
+    else
     VFIK_WAIT_VM(N_SLOT);  // goal block has landed
     {
         double gq[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) read_quad<T>(region, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP, lanec, gq + 4 * k);
+        for (int k = 0; k < 4; ++k) read_quad<T>(dreg, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP, lanec, gq + 4 * k);
         speed = gq[15];
         {   // goal block = the arm's lowest-id attractor: [frame rows 0..2 | present, slow, force, speedScale]
             double GR[9], Gp[3];
@@ -1039,6 +1297,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int n0 = a.fast_order;
             // One chunk = PRE slots: read them out of LDS, then -- before the arithmetic -- request the
             // next chunk into the same rows, so that its latency hides behind this chunk's math.
+            // One chunk = PRE slots: read them out of LDS, then -- before the arithmetic -- request the
+            // next chunk into the same rows, so that its latency hides behind this chunk's math.
+            // (Round 3 tried the first chunk in two halves, each behind its own counted wait, so that the second half's
+            // arrival would hide behind the first half's arithmetic when the inputs come from HBM: +2.4 % cold, +1 % warm
+            // -- the eight slots in lock step are worth more than the overlap; profiles/r03_ab_experiments.md.)
             auto chunk = [&](int c0) {
                 const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
                 double dx[PRE], dy[PRE], dz[PRE], rs[PRE], fk[PRE];
@@ -1046,7 +1309,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int k = 0; k < PRE / 2; ++k) {  // a pair of slots = three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1)
                     double v[12];
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) read_quad<T>(region, Stage<T>::slot_off(3 * k + u, NJ), lanec, v + 4 * u);
+                    for (int u = 0; u < 3; ++u) read_quad<T>(dreg, Stage<T>::slot_off(3 * k + u, NJ), lanec, v + 4 * u);
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const int m = 2 * k + hf;
@@ -1063,7 +1326,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < QPC; ++idx) {
                         const int m = c0 + PRE + 2 * (idx / 3);  // first slot of the quad's pair
                         const char* sm = sg + (m < a.slots_used ? (long)((c0 + PRE) / 2 * 3 + idx) * planeB : 0);
-                        stage_quad<T, NTL>(sm, region, Stage<T>::slot_off(idx, NJ));
+                        stage_quad<T, NTL>(sm, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 double di[PRE], rb[PRE], rp[PRE];
@@ -1095,7 +1358,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     tot[0] += dx[m] * k; tot[1] += dy[m] * k; tot[2] += dz[m] * k;
                 }
             };
-            VFIK_WAIT_VM(0);  // the first chunk (requested during the kinematics) has landed
+            // the first chunk (requested during the kinematics, or -- PERS -- at the start of the launch / under the previous
+            // chunk of arms) has landed; PERS: the requests of the wave's NEXT chunk of arms are younger and stay out
+            if (PERS && has_next) VFIK_WAIT_VM(NPF);
+            else VFIK_WAIT_VM(0);
             chunk(0);
             // further chunks: kept out of line of the first so that the common (<= PRE slots) case is
             // straight-line code with no loop-carried register shuffling
@@ -1108,7 +1374,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             // PRE slots are read from the rows staged in LDS during the kinematics -- read from memory, every
             // slot cost a round trip of its own (C3 with one odd arm: 10.9 us per launch) -- the rest, and
             // entries that would straddle the staged window, from the quad planes.
-            const SlotLds<T> rl{region, lanec, NJ};
+            const SlotLds<T> rl{dreg, lanec, NJ};
             const double rs = kc->rot_slow, csl = kc->cos_slow;
             for (int c0 = 0; c0 < a.slots_used; c0 += PRE) {  // chunks of PRE slots through the staged rows
                 if (c0 > 0) {  // (no overlap with the previous chunk's arithmetic here: its entries read the rows lazily)
@@ -1117,7 +1383,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int idx = 0; idx < 2 * PRE; ++idx) {
                         const int m = c0 + (idx >> 1);
                         const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-                        stage_quad<T, NTL>(sm, region, Stage<T>::slot_off(idx, NJ));
+                        stage_quad<T, NTL>(sm, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 VFIK_WAIT_VM(0);
@@ -1135,8 +1401,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                     for (int m = 0; m < PRE; ++m) {
                         double s0[4], s1[4];
-                        read_quad<T>(region, Stage<T>::slot_off(2 * m, NJ), lanec, s0);
-                        read_quad<T>(region, Stage<T>::slot_off(2 * m + 1, NJ), lanec, s1);
+                        read_quad<T>(dreg, Stage<T>::slot_off(2 * m, NJ), lanec, s0);
+                        read_quad<T>(dreg, Stage<T>::slot_off(2 * m + 1, NJ), lanec, s1);
                         const int n = (int)s1[1];
                         const bool ok = m < ncur && (int)s1[3] == VFIK_FIELD_REPELLER && (double)n == s1[1] && n >= 0 && n < 128;
                         dx[m] = s0[0] - pt[0]; dy[m] = s0[1] - pt[1]; dz[m] = s0[2] - pt[2];
@@ -1185,6 +1451,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     PIN_ARR(tot, 6);
     STAMP(5);
+    // The nullspace state is requested HERE, a phase ahead of the module that uses it (the IK's solve covers the round trip;
+    // requested in front of the Gram-Schmidt block, as in round 2, the launch is 2.0 % slower with the inputs in HBM, 0.3 %
+    // with them in the Infinity Cache: profiles/r03_ab_experiments.md).  A rollout loads it once, before its cycles.
+    if constexpr (NULLSP && NJ <= 7 && !ROLL) load_null_state();
     // normCart + speedScale * scalars (vf:292,346-347)
     double v[3], w[3];
     {
@@ -1211,7 +1481,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = PLAIN ? tw[i] : (wts ? wts[(long)i * wpitch] : kc->wy[i]) * tw[i];
+            double t = PLAIN ? tw[i] : wyv[PLAIN ? 0 : i] * tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -1263,26 +1533,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int k = i + 1; k < 6; ++k) wn[i] = __builtin_fma(-Gm[FUSEP ? k : 0][i], wn[k], wn[i]);
         }
+        if constexpr (!PLAIN) {  // qdot = Wq^2 J^T (Wy y)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) y[r] *= wyv[PLAIN ? 0 : r];
+        }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
-            qv[i] = S[i][0] * y[0];
+            qv[i] = Jm[i][0] * y[0];
             if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][0], wn[0], zp[i]);
         }
 #pragma unroll
         for (int r = 1; r < 6; ++r)
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
-                qv[i] = __builtin_fma(S[i][r], y[r], qv[i]);
+                qv[i] = __builtin_fma(Jm[i][r], y[r], qv[i]);
                 if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][r], wn[r], zp[i]);
             }
         if (!PLAIN) {
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) qv[i] *= wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i];
+            for (int i = 0; i < NJ; ++i) qv[i] *= wq2_of(i);
         }
     }
 
     PIN_ARR(qv, NJ);
     STAMP(6);
+    if constexpr (PERS) {
+        // The next chunk's inputs have landed (requested a field evaluation and an IK ago): from here on the only
+        // requests this wave leaves outstanding are its own stores, and the waits at the top of the next chunk pass.
+        if (has_next) VFIK_WAIT_VM(0);
+    }
+    if constexpr (NJ >= 10 && !ROLL) {
+        // Long chains: the joint angles are read from the wave's LDS rows AGAIN for the nullspace module, the mixer and the
+        // outputs, instead of being held in 2 n registers through the field and the IK (the 14-joint kernels spill otherwise).
+        asm volatile("" ::: "memory");
+        read_q();
+    }
     // ---------------- A10-A13: nullspace module (nullspace:95-131,162-184) ----------------------
     double qn[NJ];
 #pragma unroll
@@ -1296,170 +1581,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int i = 0; i < NJ; ++i)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
-            if constexpr (!ROLL) load_null_state();
-            // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
-            // afterwards Jm[i][r] = Jm[i][r], and I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
-            // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
-            // Right-looking order: once row s is normalised, the projections of ALL later rows onto it are
-            // independent chains (5, 4, ... of them) that a lone wave can interleave; row by row (left-looking) the
-            // same operations are one serial chain of 7-term dot products (dependent float64 ops issue every ~8
-            // cycles, independent ones every ~5).  Same arithmetic, same order per row: same results.
-            int rank = 0;
-            double n0[6];  // squared norms of the rows of J: the rank test's yardstick
-    #pragma unroll
-            for (int r = 0; r < 6; ++r) n0[r] = Jm[0][r] * Jm[0][r];
-    #pragma unroll
-            for (int i = 1; i < NJ; ++i)
-    #pragma unroll
-                for (int r = 0; r < 6; ++r) n0[r] = __builtin_fma(Jm[i][r], Jm[i][r], n0[r]);
-    #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                double n1 = 0.0;
-                if (s == 0) {
-                    n1 = n0[0];  // nothing has been projected out of the first row
-                } else {
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) n1 += Jm[i][s] * Jm[i][s];
-                }
-                const bool keep = n1 > 1e-24 * n0[s] && n0[s] > 0.0;
-                double n1r, n1i;
-                sqrt_rsqrt(n1, n1r, n1i);
-                const double inv = keep ? n1i : 0.0;
-                rank += keep ? 1 : 0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) Jm[i][s] *= inv;
-                double c[6];
-    #pragma unroll
-                for (int r = s + 1; r < 6; ++r) c[r] = 0.0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i)
-    #pragma unroll
-                    for (int r = s + 1; r < 6; ++r) c[r] += Jm[i][s] * Jm[i][r];
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i)
-    #pragma unroll
-                    for (int r = s + 1; r < 6; ++r) Jm[i][r] -= c[r] * Jm[i][s];
-            }
-            const int nullity = NJ - rank;
-            if (nullity == 1) {
-                // the unique nullspace direction: normalised column of the projector with the largest diagonal
-                double best = -1.0;
-                int ib = 0;
-                double u[NJ];
-                // u <- (I - Q^T Q) u: all six coefficients first (independent dot products), then the update (classical
-                // Gram-Schmidt against an orthonormal Q); returns the largest |coefficient| = how much of u was row space
-                auto project = [&]() {
-                    double c[6];
-    #pragma unroll
-                    for (int r = 0; r < 6; ++r) c[r] = 0.0;
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i)
-    #pragma unroll
-                        for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * u[i];
-    #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-    #pragma unroll
-                        for (int i = 0; i < NJ; ++i) u[i] -= c[r] * Jm[i][r];
-                    double cm = fabs(c[0]);
-    #pragma unroll
-                    for (int r = 1; r < 6; ++r) cm = fmax(cm, fabs(c[r]));
-                    return cm;
-                };
-                double nn = 0.0;
-                // Warm start: the nullspace direction turns little between two control cycles, so last cycle's vector
-                // (the sign memory, nullspace:92,104) is projected instead of a unit vector: no search for the best
-                // unit vector, and ONE projection suffices when it removes little (its residual row-space part is
-                // ~ eps cond(J) times what was removed).  Any lane without a usable previous vector (first cycle, a
-                // jump) sends its wave down the cold path below.
-                bool warm = false;
-                {
-                    if (__all(has_vec)) {  // (a stored vector is a unit vector)
-    #pragma unroll
-                        for (int i = 0; i < NJ; ++i) u[i] = lv_r[i];
-                        const double cm = project();
-    #pragma unroll
-                        for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
-                        if (__all(nn > 0.25)) {
-                            warm = true;
-                            if (__any(cm > 1e-2)) {  // a real move: project once more, as the cold path does
-                                project();
-                                nn = 0.0;
-    #pragma unroll
-                                for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
-                            }
-                        }
-                    }
-                }
-                if (!warm) {
-                    double dg[NJ];
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) dg[i] = 1.0;
-    #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-    #pragma unroll
-                        for (int i = 0; i < NJ; ++i) dg[i] -= Jm[i][r] * Jm[i][r];
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i)
-                        if (dg[i] > best) { best = dg[i]; ib = i; }
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) u[i] = (i == ib) ? 1.0 : 0.0;
-                    project();  // twice: the second pass squares the residual
-                    project();
-                    nn = 0.0;
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) nn += u[i] * u[i];
-                }
-                double nrm, ninv;
-                sqrt_rsqrt(nn, nrm, ninv);
-                // All three sign decisions are taken on the un-normalised u and applied with the normalisation, in one
-                // multiplication per joint.  (1) The raw vector v as LAPACK's SVD leaves it: the first component that is
-                // not negligible (|v_i| > 1e-9 of the unit vector) is negative (oracle + golden).
-                const double thr = 1e-9 * nrm;
-                bool found = false, negate = false;  // negate: v = -u / |u|
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i)
-                    if (!found && fabs(u[i]) > thr) { found = true; negate = u[i] > 0.0; }
-                // (2) sign continuity against the previous cycle (nullspace:101-105): sig flips when sig v is farther from
-                // lastvec than -sig v; |sig v - l|^2 - |sig v + l|^2 = -4 sig (v . l), so only the sign of v . l counts
-                double dot = 0.0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) dot += u[i] * lv_r[i];
-                int sig = sig_r;
-                const double vl = negate ? -dot : dot;
-                if ((sig < 0 ? -vl : vl) < 0.0) sig = -sig;
-                sig_r = sig;
-                has_vec = true;
-                const double k = (negate != (sig < 0)) ? -ninv : ninv;
-                double c0 = 0.0;
-                if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    u[i] *= k;
-                    lv_r[i] = u[i];
-                    qn[i] = u[i] * c0;  // move_in_nullspace (nullspace:113-117): min(n, 4, 1) = 1 row
-                }
-                if constexpr (!ROLL) {
-                    if (act) store_null_state();
-                }
-            } else if (nullity >= 2) {
-                status |= VFIK_ST_NULL_AMBIGUOUS;  // SVD basis not unique: /control cannot be honoured
-            }
-            if (a.flags & VFIK_F_JOINT_LIMIT_TASK) {
-                double z[NJ];
-                jl_descent(z);
-                double c[6];
-    #pragma unroll
-                for (int r = 0; r < 6; ++r) c[r] = 0.0;
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i)
-    #pragma unroll
-                    for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * z[i];
-    #pragma unroll
-                for (int r = 0; r < 6; ++r)
-    #pragma unroll
-                    for (int i = 0; i < NJ; ++i) z[i] -= c[r] * Jm[i][r];
-    #pragma unroll
-                for (int i = 0; i < NJ; ++i) qn[i] += z[i];
+            double c0 = 0.0;
+            if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
+            const bool advanced = nullspace_core<NJ>(Jm, lv_r, sig_r, has_vec, c0, (a.flags & VFIK_F_JOINT_LIMIT_TASK) != 0, jl_descent, qn, status);
+            if constexpr (!ROLL) {
+                if (advanced && act) store_null_state();
             }
         } else {
             // n >= 8: the nullspace of a 6 x n Jacobian has dimension >= 2, so the reference's SVD basis is
@@ -1562,69 +1688,101 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
     if ((!ROLL || cyc == ncyc - 1) && act) {  // the outputs are those of the last evaluated cycle
         // ---------------- outputs (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73) --
-        if (a.qdot_out) {
-            T* o = static_cast<T*>(a.qdot_out) + (long)arm * NJ;
-            if (!ROLL && a.q_cmded && !direct) {  // LWR command form (bridge:199-203): -last_qcmded + last_q + qdot_lim
-                const T* qc = static_cast<const T*>(a.q_cmded) + (long)arm * NJ;
+        // Every output is batch-major ([B][K]: the reference publishes a bottle of K numbers per arm), so a lane's K values
+        // are contiguous and the 64 lanes of a store instruction hit 64 different places K elements apart: 61 such
+        // instructions for everything vf / nullspace / debug publish cost the C3 batch 3.5 us (7 700 cycles per wave,
+        // tools/stamps.py C3F).  The wave's 64 rows are ONE contiguous tile of 64 K elements: it is assembled in LDS (the
+        // goal block's rows, dead by now) and written with 16 bytes per lane, 1 KiB per instruction.  Not for LEAN launches
+        // (seven stores in all), gated launches (a silent arm's row must stay), the batch's last partial wave, or output
+        // pointers that are not 16-byte aligned: those store lane by lane.
+        const bool tiles = LEAN == 0 && !a.active && (arm - lanec) + 64 <= a.B;
+        auto put_rows = [&](void* out, auto kconst, auto&& val) {   // out[arm][i] = val(i), i < K
+            constexpr int K = decltype(kconst)::value;
+            T* const o = static_cast<T*>(out);
+            if (tiles && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0) {  // wave-uniform
+                char* const tile = dreg + Stage<T>::GOAL_OFF;   // 64 x 16 elements at most: 4 QSTEP
+                T* const mine = reinterpret_cast<T*>(tile) + lanec * K;
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) o[i] = (T)((-(double)qc[i] + q[i]) + qo[i]);
+                for (int i = 0; i < K; ++i) mine[i] = (T)val(i);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's rows are in LDS (in-order LDS queue; nothing may move across)
+                constexpr int PIECES = 64 * K * (int)sizeof(T) / 16;
+                char* const g = reinterpret_cast<char*>(o + (long)(arm - lanec) * K);
+    #pragma unroll
+                for (int it = 0; it * 64 < PIECES; ++it) {
+                    const int pc = it * 64 + lanec;
+                    if (PIECES % 64 == 0 || it * 64 + 64 <= PIECES || pc < PIECES)
+                        *reinterpret_cast<f4s*>(g + (long)pc * 16) = *reinterpret_cast<const f4s*>(tile + pc * 16);
+                }
+                asm volatile("" ::: "memory");
             } else {
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) o[i] = (T)qo[i];
+                for (int i = 0; i < K; ++i) o[(long)arm * K + i] = (T)val(i);
+            }
+        };
+        typedef std::integral_constant<int, NJ> KNJ;
+        // (every put_rows call sits in wave-uniform control flow: with `tiles` all 64 lanes assemble the tile together)
+        if (a.qdot_out) {
+            if (!ROLL && a.q_cmded) {  // LWR command form (bridge:199-203): -last_qcmded + last_q + qdot_lim, unless direct_control
+                const T* qc = static_cast<const T*>(a.q_cmded) + (long)arm * NJ;
+                double cmd[NJ];
+    #pragma unroll
+                for (int i = 0; i < NJ; ++i) cmd[i] = direct ? qo[i] : (-(double)qc[i] + q[i]) + qo[i];
+                put_rows(a.qdot_out, KNJ(), [&](int i) { return cmd[i]; });
+            } else {
+                put_rows(a.qdot_out, KNJ(), [&](int i) { return qo[i]; });
             }
         }
-        if (a.qdot_vf) {
-            T* o = static_cast<T*>(a.qdot_vf) + (long)arm * NJ;
-    #pragma unroll
-            for (int i = 0; i < NJ; ++i) o[i] = (T)qv[i];
-        }
-        if (a.qdot_null) {
-            T* o = static_cast<T*>(a.qdot_null) + (long)arm * NJ;
-    #pragma unroll
-            for (int i = 0; i < NJ; ++i) o[i] = (T)qn[i];
-        }
-        if (a.pose) {
-            T* o = static_cast<T*>(a.pose) + (long)arm * 16;
-    #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-    #pragma unroll
-                for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)Rt[3 * r + c];
-                o[4 * r + 3] = (T)pt[r];
-            }
-            o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
-        }
+        if (a.qdot_vf) put_rows(a.qdot_vf, KNJ(), [&](int i) { return qv[i]; });
+        if (a.qdot_null) put_rows(a.qdot_null, KNJ(), [&](int i) { return qn[i]; });
+        // (Round 3 tried pose / pose_no_tool / qdist right behind the read of the goal block, so that their writes would drain
+        // under the field and the IK: C3F +-0 -- the wave pays the same ~1 100 cycles a 16-column tile wherever they sit --
+        // and C5F 16.7 -> 18.2 us: the 14-joint kernel then spills.  They stay in the epilogue.)
+        if (a.pose)
+            put_rows(a.pose, std::integral_constant<int, 16>(), [&](int i) {
+                return i < 12 ? ((i & 3) == 3 ? pt[i >> 2] : Rt[3 * (i >> 2) + (i & 3)]) : (i == 15 ? 1.0 : 0.0);
+            });
         if (a.pose_nt) {
-            T* o = static_cast<T*>(a.pose_nt) + (long)arm * 16;
-    #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-    #pragma unroll
-                for (int c = 0; c < 3; ++c) o[4 * r + c] = (T)R[3 * r + c];
-                o[4 * r + 3] = (T)p[r];
+            if constexpr (!PLAIN && NJ >= 10) {
+                // Long chains: the flange frame is recomposed from the tool pose, R = Rt Rtool^T and p = pt + (p_ee - p_tip),
+                // instead of living in 12 double registers through the field and the IK beside Rt / pt (scratch otherwise).
+                double tl[12];
+                if (a.tool_stride) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) read_quad<T>(region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP, lanec, tl + 4 * k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) tl[k] = kc->tool[k];
+                }
+                double Rf[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rf[3 * r + c] = Rt[3 * r] * tl[4 * c] + Rt[3 * r + 1] * tl[4 * c + 1] + Rt[3 * r + 2] * tl[4 * c + 2];
+                put_rows(a.pose_nt, std::integral_constant<int, 16>(), [&](int i) {
+                    return i < 12 ? ((i & 3) == 3 ? pt[i >> 2] + rr[i >> 2] : Rf[3 * (i >> 2) + (i & 3)]) : (i == 15 ? 1.0 : 0.0);
+                });
+            } else {
+                put_rows(a.pose_nt, std::integral_constant<int, 16>(), [&](int i) {
+                    return i < 12 ? ((i & 3) == 3 ? p[i >> 2] : R[3 * (i >> 2) + (i & 3)]) : (i == 15 ? 1.0 : 0.0);
+                });
             }
-            o[12] = o[13] = o[14] = (T)0.0; o[15] = (T)1.0;
         }
-        if (a.v6) {
-            T* o = static_cast<T*>(a.v6) + (long)arm * 6;
-    #pragma unroll
-            for (int k = 0; k < 3; ++k) { o[k] = (T)v[k]; o[3 + k] = (T)w[k]; }
-        }
+        if (a.v6) put_rows(a.v6, std::integral_constant<int, 6>(), [&](int i) { return i < 3 ? v[i] : w[i - 3]; });
         if (a.qdist) {
-            T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
+            double dc[NJ];
             if (a.q_lo) {
                 double lo[NJ], hi[NJ];
                 limits_of(lo, hi);
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - 0.5 * (lo[i] + hi[i])) * rcp_nr(0.5 * (hi[i] - lo[i])));
+                for (int i = 0; i < NJ; ++i) dc[i] = fabs(q[i] - 0.5 * (lo[i] + hi[i])) * rcp_nr(0.5 * (hi[i] - lo[i]));
             } else {
     #pragma unroll
-                for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+                for (int i = 0; i < NJ; ++i) dc[i] = fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i];
             }
+            put_rows(a.qdist, KNJ(), [&](int i) { return dc[i]; });
         }
-        if (a.goal_dist) {  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
-            T* o = static_cast<T*>(a.goal_dist) + (long)arm * 2;
-            o[0] = (T)gdist[0];
-            o[1] = (T)(gdist[1] * 57.295779513082320877);
-        }
+        if (a.goal_dist)  // /dmonitor/distOut entry of object 0: xyz distance, rotation angle in DEGREES (monitor_distance:76-84,161-172)
+            put_rows(a.goal_dist, std::integral_constant<int, 2>(), [&](int i) { return i == 0 ? gdist[0] : gdist[1] * 57.295779513082320877; });
     }
     if (ROLL || a.q_out) {  // joint_sim: integrate the commanded velocity; optionally stay inside the joint limits
 #pragma unroll
@@ -1637,15 +1795,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     }
     }  // cycles of this launch
-    if (!act) return;  // (no store has been made for this arm)
-    if constexpr (NULLSP && ROLL && NJ <= 7) store_null_state();
-    if (a.q_out) {
-        T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
+    if (act) {  // (else no store has been made for this arm)
+        if constexpr (NULLSP && ROLL && NJ <= 7) store_null_state();
+        if (a.q_out) {
+            T* o = static_cast<T*>(a.q_out) + (long)arm * NJ;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) o[i] = (T)q[i];
+            for (int i = 0; i < NJ; ++i) o[i] = (T)q[i];
+        }
+        if (a.status) a.status[arm] = a.status_or ? (a.status[arm] | status) : status;
     }
-    if (a.status) a.status[arm] = a.status_or ? (a.status[arm] | status) : status;
     STAMP(7);
+    if constexpr (!PERS) {
+        break;
+    } else {
+        if (!has_next) break;
+        chunk += (int)gridDim.x;
+        const int an = chunk * 64 + (int)threadIdx.x;
+        act = an < a.B;
+        arm = arm_next;
+        sg = slots0 + (long)arm * QB;
+        dreg = dreg_next;
+    }
+    }  // chunks of this wave (PERS)
 }
 
 // CommandMixer.read's weighted sum alone (command_mixer.py:78-82): out = sum_k cmd[k] * w[k], left to
@@ -1814,21 +1985,28 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
 
 // ------------------------------------------------------------------------------------------------
 // EIGHT LANES PER ARM (small batches): the mapping BASELINE.json's north_star sketches -- an arm spread over the lanes of
-// a (sub-)wave with cross-lane exchange -- for the common lean launch (revolute chain of up to 7 joints, identity
-// tool, unit weights, goal + integer-order decay repellers, no module flag, qdot_out / status only).  A wave holds 8
-// arms; lane j of an arm's group of 8
+// a (sub-)wave with cross-lane exchange -- for what vfclik itself runs: a handful of arms (scripts/vfclik:88-105), each
+// with its vf, nullspace and debug process and the bridge's mixer.  Served: revolute chain of up to 7 joints, identity
+// tool, unit weights, goal + integer-order decay repellers; NS = the nullspace module (+ joint-limit task), mixer and
+// limiter by the launch's flags, /control; outputs qdot_out, qdotOut, qdotout, pose, pose_no_tool, qdist, status -- what
+// the per-arm processes publish every cycle (vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73).
+// A wave holds 8 arms; lane j of an arm's group of 8
 //   * computes sin / cos of joint j                                   (1 angle per lane instead of 7 in sequence),
-//   * evaluates the repellers j, j + 8, ...                           (1 slot per lane per round instead of 8),
-//   * stores joint j of the result;
-// the serial spine -- the chained joint transforms, the attractor, J J^T, the 6 x 6 LDL^T, the two triangular solves --
-// is replicated on all 8 lanes (it does not parallelise: DESIGN.md section 5.1), and the group exchanges through 1 KiB of
-// LDS per arm (sin / cos, the repellers' sum, the result).  With 4 096 arms the launch has 512 waves instead of 64.
-// Plain loads: a batch this small has no bandwidth to stage for.  Same arithmetic as cycle_kernel up to the order of
-// the field sum.
+//   * evaluates the repellers j, j + 8, ...                           (1 slot per lane per round instead of 8);
+// everything else is replicated on the 8 lanes: the chained joint transforms, the attractor, the 6 x 6 LDL^T and its
+// solves are serial, and what is parallel in form -- the 21 entries of J J^T, the rows of J^T y, the Gram-Schmidt
+// projections -- would need every lane to pick ITS operands out of register arrays that all lanes hold alike (a chain of
+// selects per operand), or the sums to cross lanes: measured on a lone wave (tools/ubench_xlane.hip) a 7-term float64 dot
+// product costs 38-42 cycles replicated, 58-77 as a DPP reduction over 8 lanes (gfx950 has no DPP form of the 64-bit
+// VALU ops: every double moves as two 32-bit DPP moves), 141-195 through LDS.  Exchange through 1 KiB of LDS per arm
+// (sin / cos, the repellers' partial sums), without barriers: the wave is the workgroup and its LDS queue is in order.
+// With 4 096 arms the launch has 512 waves instead of 64.  Plain loads: a batch this small has no bandwidth to stage
+// for.  Same arithmetic as cycle_kernel up to the order of the field sum; lane 0 of each group stores the arm's rows.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NJ>
+#define VFIK_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // one wave per block: in-order LDS queue, no s_barrier needed
+template <typename T, int NJ, bool NS>
 __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
-    static_assert(NJ <= 8, "one lane per joint");
+    static_assert(NJ <= 8 && (!NS || NJ <= 7), "one lane per joint; the sign memory is for chains of up to 7 joints");
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, j = lane & 7;
     const int arm_raw = blockIdx.x * 8 + g;
@@ -1840,6 +2018,7 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
     const KcPtr kc = (KcPtr)(unsigned long long)a.kc;
     const KConst<NJ>* const kv = static_cast<const KConst<NJ>*>(a.kc);  // the same block through vector loads (lane-indexed)
     const long Bp = a.Bpad;
+    const unsigned flags = NS ? a.flags : 0u;
     int status = 0;
 
     // ---- loads: joint angle of this lane, goal block (every lane of the group), this lane's first repeller
@@ -1866,6 +2045,26 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
     };
     double s8[8];
     load_slot(j, s8);
+    // nullspace state (as cycle_kernel keeps it: floats, (n + 4) / 4 planes) and /control, requested up front
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    constexpr int NS_PLANES = (NJ + 4) / 4;
+    int sig_r = 1;
+    bool has_vec = false;
+    double lv_r[NJ], c0 = 0.0;
+    if constexpr (NS) {
+        const f4s* sp = reinterpret_cast<const f4s*>(a.lastvec) + arm;
+        float sv[NS_PLANES * 4];
+#pragma unroll
+        for (int k = 0; k < NS_PLANES; ++k) {
+            const f4s v = sp[(long)k * a.Bpad];
+            sv[4 * k] = v.x; sv[4 * k + 1] = v.y; sv[4 * k + 2] = v.z; sv[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) lv_r[i] = (double)sv[i];
+        sig_r = sv[NJ] < 0.0f ? -1 : 1;
+        has_vec = fabsf(sv[NJ]) > 1.5f;
+        if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
+    }
 
     // ---- A3: sin / cos of joint j on lane j, exchanged through LDS
     {
@@ -1873,11 +2072,12 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
         sincos_fast(qj + offj, sj, cj);
         L[2 * j] = sj;
         L[2 * j + 1] = cj;
+        L[32 + j] = qj;  // ... and the joint angles themselves (check_limits, distToCenter)
     }
-    __syncthreads();
-    double sn[NJ], cs[NJ];
+    VFIK_WAVE_LDS_SYNC();
+    double sn[NJ], cs[NJ], q[NJ];
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) { sn[i] = L[2 * i]; cs[i] = L[2 * i + 1]; }
+    for (int i = 0; i < NJ; ++i) { sn[i] = L[2 * i]; cs[i] = L[2 * i + 1]; q[i] = L[32 + i]; }
     // the chain, replicated (constants through the scalar cache)
     double R[9], p[3];
 #pragma unroll
@@ -1925,9 +2125,8 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
         const double k = s8[6] * fmin(powi_uniform(rb, n0), MAG_CAP) * di;
         part[0] += dx * k; part[1] += dy * k; part[2] += dz * k;
     }
-    __syncthreads();  // (the sin / cos values have been read)
-    L[16 + 4 * j] = part[0]; L[16 + 4 * j + 1] = part[1]; L[16 + 4 * j + 2] = part[2];
-    __syncthreads();
+    L[64 + 4 * j] = part[0]; L[64 + 4 * j + 1] = part[1]; L[64 + 4 * j + 2] = part[2];  // (a region of its own: no hazard with the reads above)
+    VFIK_WAVE_LDS_SYNC();
     double tot[6] = {0, 0, 0, 0, 0, 0}, sc[2] = {1.0, 1.0}, gdist[2];
     {
         double GR[9], Gp[3];
@@ -1940,7 +2139,7 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
         attractor(R, p, GR, Gp, gq[13], gq[14], kc->rot_slow, kc->cos_slow, gq[12] != 0.0, tot, sc, gdist);
     }
 #pragma unroll
-    for (int l = 0; l < 8; ++l) { tot[0] += L[16 + 4 * l]; tot[1] += L[16 + 4 * l + 1]; tot[2] += L[16 + 4 * l + 2]; }
+    for (int l = 0; l < 8; ++l) { tot[0] += L[64 + 4 * l]; tot[1] += L[64 + 4 * l + 1]; tot[2] += L[64 + 4 * l + 2]; }
     double tw[6];
     {
         double nt, nti, nr, nri;
@@ -1999,19 +2198,127 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
         for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k];
         y[i] = t;
     }
-    int nan = 0;
+    double qv[NJ], qn[NJ], qo[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
-        double qv = Jm[i][0] * y[0];
+        qv[i] = Jm[i][0] * y[0];
 #pragma unroll
-        for (int r = 1; r < 6; ++r) qv = __builtin_fma(Jm[i][r], y[r], qv);
-        nan |= (int)(qv != qv);
-        L[64 + i] = qv;  // (all 8 lanes hold the same value)
+        for (int r = 1; r < 6; ++r) qv[i] = __builtin_fma(Jm[i][r], y[r], qv[i]);
+        qn[i] = 0.0;
     }
+
+    // ---- A10-A13: nullspace module, A15: mixer and limiter (replicated; the same code as cycle_kernel)
+    bool advanced = false;
+    if constexpr (NS) {
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));  // the IK is done with J before it is orthonormalised
+        advanced = nullspace_core<NJ>(Jm, lv_r, sig_r, has_vec, c0, (flags & VFIK_F_JOINT_LIMIT_TASK) != 0,
+                                      [&](double* z) {
+#pragma unroll
+                                          for (int i = 0; i < NJ; ++i) z[i] = -kc->jl_k[i] * (q[i] - kc->q_mid[i]);
+                                      },
+                                      qn, status);
+        const double look = kc->lookahead, ngain = kc->null_gain;
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const double d = q[i] + look * qn[i];
+            bad |= (int)(d < kc->q_lo[i]) | (int)(d > kc->q_hi[i]);
+        }
+        const bool stop = bad != 0;
+        if (stop) status |= VFIK_ST_LIMIT_STOP;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) qn[i] = stop ? 0.0 : qn[i] * ngain;
+    }
+    if (flags & VFIK_F_MIXER) {
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) qo[i] = mac_unfused(mul_unfused(qv[i], kc->mix_w[0]), qn[i], kc->mix_w[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) qo[i] = qv[i];
+    }
+    if (flags & VFIK_F_LIMITER) {
+        double lead = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) lead = fmax(lead, fabs(qo[i]));
+        if (lead > kc->max_vel) {
+            const double ratio = kc->max_vel * rcp_nr(lead);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) qo[i] *= ratio;
+            status |= VFIK_ST_LIMITED;
+        }
+    }
+    int nan = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) nan |= (int)(qo[i] != qo[i]);
     if (nan) status |= VFIK_ST_NAN;
-    __syncthreads();
-    if (live && j < NJ) static_cast<T*>(a.qdot_out)[(long)arm * NJ + j] = (T)L[64 + j];
-    if (live && j == 0 && a.status) a.status[arm] = status;
+
+    // ---- outputs: every lane of the group holds the arm's results.  The mixed command goes through the arm's LDS area so that
+    // lane j stores joint j (one store instruction for the wave); the other rows are stored by lane 0 of the group, element by
+    // element.  (All rows through LDS, lanes j and j + 8 storing their elements: 0.4-0.6 us SLOWER at 1-512 arms -- two more
+    // LDS round trips on a lone wave's critical path -- and no faster at 4 096; profiles/r03_latency_small_*.txt.)
+    VFIK_WAVE_LDS_SYNC();  // (the area's earlier contents have been read)
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) L[i] = qo[i];  // (all 8 lanes hold the same value)
+    VFIK_WAVE_LDS_SYNC();
+    if (live && j < NJ) static_cast<T*>(a.qdot_out)[(long)arm * NJ + j] = (T)L[j];
+    if (live && j == 0) {
+        if (a.qdot_vf) {
+            T* o = static_cast<T*>(a.qdot_vf) + (long)arm * NJ;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)qv[i];
+        }
+        if (a.qdot_null) {
+            T* o = static_cast<T*>(a.qdot_null) + (long)arm * NJ;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)qn[i];
+        }
+        if (a.pose || a.pose_nt) {  // identity tool: one frame
+            T fr[16];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fr[4 * r + c] = (T)R[3 * r + c];
+                fr[4 * r + 3] = (T)p[r];
+            }
+            fr[12] = fr[13] = fr[14] = (T)0.0; fr[15] = (T)1.0;
+            if (a.pose) {
+                T* o = static_cast<T*>(a.pose) + (long)arm * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = fr[i];
+            }
+            if (a.pose_nt) {
+                T* o = static_cast<T*>(a.pose_nt) + (long)arm * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = fr[i];
+            }
+        }
+        if (a.qdist) {
+            T* o = static_cast<T*>(a.qdist) + (long)arm * NJ;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) o[i] = (T)(fabs(q[i] - kc->q_mid[i]) * kc->inv_half[i]);
+        }
+        if (a.status) a.status[arm] = status;
+        if constexpr (NS) {
+            if (advanced) {  // the sign memory, as cycle_kernel stores it
+                f4s* sp = reinterpret_cast<f4s*>(a.lastvec) + arm;
+                float sv[NS_PLANES * 4];
+#pragma unroll
+                for (int i = 0; i < NS_PLANES * 4; ++i) sv[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) sv[i] = (float)lv_r[i];
+                sv[NJ] = (float)sig_r * (has_vec ? 2.0f : 1.0f);
+#pragma unroll
+                for (int k = 0; k < NS_PLANES; ++k) {
+                    f4s v;
+                    v.x = sv[4 * k]; v.y = sv[4 * k + 1]; v.z = sv[4 * k + 2]; v.w = sv[4 * k + 3];
+                    sp[(long)k * a.Bpad] = v;
+                }
+            }
+        }
+    }
 }
 
 template <typename T, int NJ, bool NS, bool PL>
@@ -2043,12 +2350,28 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
             return;
         }
     }
-    if constexpr (PL && !NS && NJ <= 8) {
-        // small lean batches: eight lanes per arm (cycle_sub8_kernel).  VFIK_SUB8_MAX_BATCH = 0 switches it off.
-        if (lean && !a.q_out && a.n_cycles == 0 && a.qdot_out && a.B <= a.sub8_max_batch) {
+    if constexpr (PL && NJ <= (NS ? 7 : 8)) {
+        // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
+        // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
+        const bool served = fastf && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
+                            !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
+                            (NS || (a.flags == 0 && !a.null_control)) && a.B <= (lean ? a.sub8_max_batch : a.sub8_max_batch_full);
+        if (served) {
             const dim3 g8((a.B + 7) / 8), b8(64);
-            hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ>), g8, b8, 8 * 1024, stream, a);
+            hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
             if (sub8) *sub8 = 1;
+            return;
+        }
+    }
+    if constexpr (PL && sizeof(T) == 4 && NJ <= 7) {
+        // Batches beyond one wave per SIMD: the persistent launch -- one wave per SIMD, each striding over the 64-arm chunks
+        // with the next chunk's inputs in flight under the current chunk's arithmetic (cycle_kernel, PERS).  Two per-arm
+        // areas per wave: lean_bytes + kin_off = 37.5 KB for 7 joints, four waves per CU.
+        const long nchunks = (a.B + 63) / 64;
+        if (lean && !a.q_out && a.n_cycles == 0 && a.pers && nchunks > (long)a.n_simd) {
+            const dim3 gp((unsigned)a.n_simd), bp(64);
+            const size_t lds_p = Stage<T>::lean_bytes(NJ) + Stage<T>::kin_off(NJ);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, true>), gp, bp, lds_p, stream, a);
             return;
         }
     }

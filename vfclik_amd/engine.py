@@ -22,11 +22,12 @@ class IO(C.Structure):
                 ("qdot_out", C.c_void_p), ("pose", C.c_void_p), ("pose_nt", C.c_void_p), ("v6", C.c_void_p),
                 ("qdist", C.c_void_p), ("status", C.c_void_p), ("goal_dist", C.c_void_p),
                 ("q_ref", C.c_void_p), ("q_cmded", C.c_void_p),
-                ("active", C.c_void_p), ("q_lo", C.c_void_p), ("q_hi", C.c_void_p), ("q_ref_out", C.c_void_p)]
+                ("active", C.c_void_p), ("q_lo", C.c_void_p), ("q_hi", C.c_void_p), ("q_ref_out", C.c_void_p),
+                ("track_error", C.c_void_p), ("obj_dist", C.c_void_p)]
 
 
 _OUT_SHAPES = {"qdot_vf": "n", "qdot_null": "n", "qdot_out": "n", "pose": 16, "pose_nt": 16, "v6": 6, "qdist": "n",
-               "goal_dist": 2, "q_ref_out": "n"}
+               "goal_dist": 2, "q_ref_out": "n", "track_error": 8}
 _lib = None
 
 
@@ -87,6 +88,7 @@ def load_library(path=None):
         "vfik_set_max_vel": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "vfik_probe_field": (C.c_int, [H, C.c_void_p, C.c_void_p]),
         "vfik_object_distances": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+        "vfik_set_objects": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_int]),
         "vfik_set_small_batch_kernel": (C.c_int, [H, C.c_int]),
         "vfik_small_batch_launches": (C.c_long, [H]),
     }
@@ -139,6 +141,7 @@ class Engine:
         self.params = params if params is not None else _abi.default_params()
         self._chk(self.lib.vfik_set_params(self.h, C.byref(self.params)))
         self._torch_out = {}
+        self.n_objects = 0  # object frames of the distance monitor held by the handle (set_objects)
 
     # -- plumbing -------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -194,6 +197,15 @@ class Engine:
         c = np.ascontiguousarray(counts, dtype=np.int32)
         self._chk(self.lib.vfik_set_fields(self.h, int(first_arm), f.shape[0], f.ctypes.data, f.shape[1], c.ctypes.data))
 
+    def set_objects(self, frames, first_arm=0):
+        """Object frames of the distance monitor (monitor_distance:72,111-129): (n_arms, n_objects, 16) doubles, kept on the
+        device; a cycle call that asks for ``obj_dist`` then gets every arm's distance / angle to its objects."""
+        f = np.ascontiguousarray(frames, dtype=np.float64)
+        if f.ndim != 3 or f.shape[2] != 16:
+            raise ValueError("frames must be (n_arms, n_objects, 16)")
+        self._chk(self.lib.vfik_set_objects(self.h, int(first_arm), f.shape[0], f.ctypes.data, f.shape[1]))
+        self.n_objects = f.shape[1]
+
     def set_mixer_weights(self, weights, first_arm=0):
         """Per-arm mixer weights (n_arms, 6); ``None`` returns to the batch-wide ``params.mix_w``."""
         if weights is None:
@@ -224,6 +236,10 @@ class Engine:
 
     # -- one control cycle -----------------------------------------------------------------------
     def _shape(self, key):
+        if key == "obj_dist":  # [B][n_objects][2]: one /dmonitor/distOut entry per object frame of set_objects
+            if self.n_objects < 1:
+                raise VfikError("obj_dist needs set_objects first")
+            return (self.batch, self.n_objects, 2)
         d = _OUT_SHAPES[key]
         return (self.batch, self.n if d == "n" else d)
 
@@ -328,9 +344,12 @@ class Engine:
         self._chk(self.lib.vfik_wait(self.h, int(ticket)))
 
     def rollout_host(self, q, n_cycles, dt, null_control=None, clamp=False, want=("qdot_out",), q_ref=None, active=None, q_lo=None,
-                     q_hi=None):
+                     q_hi=None, into=None):
         """n_cycles control cycles in one launch with q integrated on the device.
-        Returns the outputs of the last cycle plus ``q`` = joint angles after it."""
+        Returns the outputs of the last cycle plus ``q`` = joint angles after it.  Arms gated off by ``active`` store
+        nothing: their row of ``q`` comes back as it went in (a silent arm keeps its joint angles -- feeding the result into
+        the next rollout is the normal closed-loop use), and their rows of the other outputs keep what ``into`` (a dict of
+        arrays from an earlier call, as in :meth:`step_host`) held, zeros without it."""
         q = np.ascontiguousarray(q, dtype=self.io_dtype)
         if q.shape != (self.batch, self.n):
             raise ValueError("q must be (%d, %d), got %s" % (self.batch, self.n, q.shape))
@@ -350,9 +369,13 @@ class Engine:
             keep.append(nc)
         out = {}
         for k in want:
-            out[k] = np.zeros(self.batch, dtype=np.int32) if k == "status" else np.zeros(self._shape(k), dtype=self.io_dtype)
+            if into is not None and k in into:
+                out[k] = into[k]
+                self._check_host(k, out[k], (self.batch,) if k == "status" else self._shape(k), np.int32 if k == "status" else self.io_dtype)
+            else:
+                out[k] = np.zeros(self.batch, dtype=np.int32) if k == "status" else np.zeros(self._shape(k), dtype=self.io_dtype)
             setattr(io, k, out[k].ctypes.data)
-        out["q"] = np.zeros((self.batch, self.n), dtype=self.io_dtype)
+        out["q"] = q.copy()  # gated arms keep their angles (the kernel stores nothing for them)
         self._chk(self.lib.vfik_rollout_host(self.h, C.byref(io), int(n_cycles), float(dt), 1 if clamp else 0, out["q"].ctypes.data))
         return out
 

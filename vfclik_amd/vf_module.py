@@ -122,7 +122,7 @@ class ControlCycleBatch:
         self.ext_time = np.full((4, self.B), self.clock())
         self._ext_dirty = [False] * 4
         self.objects = [dict() for _ in range(self.B)]   # monitor_distance:72: id -> frame16, insertion-ordered
-        self._mon_bufs = None
+        self._objects_key = None
         self._probe_bufs = None
         self.q_ref = np.zeros((self.B, self.n))          # /jpctrl/ref (joint_p_controller:113-118)
         self.has_ref = np.zeros(self.B, dtype=bool)      # arms whose joint controller has a reference
@@ -133,7 +133,6 @@ class ControlCycleBatch:
         self._outs = None                                 # output arrays, reused so that gated arms keep their rows
         self.report_counter = 0  # vf:185,432-435
         self.tracking = [TrackingState() for _ in range(self.B)]
-        self._track_bufs = None
         self.last = {}
         self.ports = []
         if open_ports:
@@ -301,16 +300,31 @@ class ControlCycleBatch:
         lo = hi = None
         if self.limits_fn is not None:  # limits of THIS cycle (nullspace:167, joint_p_controller:80)
             lo, hi = self.limits_fn(self.q)
-        want = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist") + (("q_ref_out",) if ref is not None else ())
-        # only the arms whose q arrived run their cycle: the others keep their state and publish nothing
-        out = self.engine.step_host(self.q, null_control=self.control, q_ref=ref, want=want, active=got_q, q_lo=lo, q_hi=hi,
+        want = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist", "track_error") \
+            + (("q_ref_out",) if ref is not None else ())
+        # the distance monitor's object frames live on the device and are rewritten only when /dmonitor/objectsIn changed them
+        n_obj = self._push_objects()
+        if n_obj:
+            want += ("obj_dist",)
+        # only the arms whose q arrived run their cycle: the others keep their state and publish nothing.
+        # ONE call = copies in, the cycle kernel, the tracking-error estimator (vf:349-428) and the distance monitor
+        # (monitor_distance:148-167) on the cycle's own device results, copies out, ONE synchronisation.
+        # self._outs: PRIVATE persistent arrays the launch writes into, so that the rows of gated arms keep what their last
+        # own cycle left there; what is published (`out`, self.last) are copies -- a consumer that holds last cycle's
+        # dictionary (a logger, a previous-against-current comparison) never sees it change underneath
+        if self._outs is not None and "obj_dist" in self._outs and (not n_obj or self._outs["obj_dist"].shape[1] != n_obj):
+            del self._outs["obj_dist"]
+        res = self.engine.step_host(self.q, null_control=self.control, q_ref=ref, want=want, active=got_q, q_lo=lo, q_hi=hi,
                                     into=self._outs)
-        self._outs = dict(out)
+        if self._outs is None:
+            self._outs = {}
+        self._outs.update(res)   # (q_ref_out joins once some arm has a reference; its key then stays)
+        out = {k: v.copy() for k, v in res.items()}
         if ref is not None:  # the controller keeps the CLAMPED reference (joint_p_controller:121)
             upd = got_q & self.has_ref
             self.q_ref[upd] = out["q_ref_out"][upd]
-        out["track_error"] = self._track_error(out, got_q)
-        dists = out["object_dist"] = self._object_distances(out)
+        out["track_error"] = out["track_error"].astype(np.float64)
+        dists = out["object_dist"] = out.pop("obj_dist").astype(np.float64) if n_obj else None
         self.last = out
         self.report_counter += 1
         report = self.report_counter > 20  # vf:432-435
@@ -354,23 +368,22 @@ class ControlCycleBatch:
         self.probe()
         return got_q
 
-    def _track_error(self, out, got_q):
-        """The tracking-error estimator (vf:349-428) for the batch, on the device; it sits inside vf's
-        `if qInBottle` block, so only the arms of got_q append a frame."""
-        e = self.engine
-        esz = e.io_dtype.itemsize
-        if self._track_bufs is None:
-            self._track_bufs = (e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * 6 * esz), e.dev_alloc(self.B * 8 * esz),
-                                e.dev_alloc(self.B * 4))
-            e.h2d(self._track_bufs[2], np.zeros((self.B, 8), dtype=e.io_dtype))
-        d_pose, d_v6, d_out, d_act = self._track_bufs
-        e.h2d(d_pose, out["pose"])
-        e.h2d(d_v6, out["v6"])
-        e.h2d(d_act, np.ascontiguousarray(got_q, dtype=np.int32))
-        e.track_error(d_pose, d_v6, d_out, d_act)
-        res = np.zeros((self.B, 8), dtype=e.io_dtype)
-        e.d2h(res, d_out)
-        return res.astype(np.float64)
+    def _push_objects(self):
+        """The distance monitor's object dictionary (monitor_distance:72,111-129) as device state: [B][O][16] with the objects
+        of every arm in the order of its dictionary, uploaded only when a message changed it.  Returns O (0: no arm knows
+        any object)."""
+        O = max(len(o) for o in self.objects)
+        if O == 0:
+            return 0
+        key = [tuple((oid, tuple(f)) for oid, f in objs.items()) for objs in self.objects]
+        if key != self._objects_key:
+            frames = np.tile(np.eye(4).reshape(16), (self.B, O, 1))
+            for a, objs in enumerate(self.objects):
+                for slot, oid in enumerate(objs):
+                    frames[a, slot] = objs[oid]
+            self.engine.set_objects(frames)
+            self._objects_key = key
+        return O
 
     def probe(self):
         """The visualisation probe of scripts/vf (vf:469-503): for every arm with a 16-value bottle waiting on
@@ -399,32 +412,6 @@ class ControlCycleBatch:
         for a in asked:
             _send(self.ports[a]["vector_out"], v6[a])
         return asked
-
-    def _object_distances(self, out):
-        """The distance monitor (monitor_distance:148-167) for the batch, on the device: [B][O][2] with the
-        objects of every arm in the order of its dictionary; None while no arm knows any object."""
-        O = max(len(o) for o in self.objects)
-        if O == 0:
-            return None
-        e = self.engine
-        frames = np.tile(np.eye(4).reshape(16), (self.B, O, 1)).astype(e.io_dtype)
-        for a, objs in enumerate(self.objects):
-            for slot, oid in enumerate(objs):
-                frames[a, slot] = objs[oid]
-        esz = e.io_dtype.itemsize
-        if self._mon_bufs is None or self._mon_bufs[0] < O:
-            if self._mon_bufs is not None:
-                for p in self._mon_bufs[1:]:
-                    e.dev_free(p)
-            cap = max(O, 4)
-            self._mon_bufs = (cap, e.dev_alloc(self.B * 16 * esz), e.dev_alloc(self.B * cap * 16 * esz), e.dev_alloc(self.B * cap * 2 * esz))
-        _, d_pose, d_frames, d_out = self._mon_bufs
-        e.h2d(d_pose, np.ascontiguousarray(out["pose"], dtype=e.io_dtype))
-        e.h2d(d_frames, frames)
-        e.object_distances(d_pose, d_frames, O, d_out)
-        res = np.zeros((self.B, O, 2), dtype=e.io_dtype)
-        e.d2h(res, d_out)
-        return res.astype(np.float64)
 
     def step_arrays(self, q, null_control=None, want=("qdot_out",), active=None, q_lo=None, q_hi=None):
         """Array path: one cycle for the whole batch without any bottle -- the way to drive thousands of arms
