@@ -251,12 +251,15 @@ int vfik_memcpy_d2h(vfik_handle* h, void* dst_host, const void* src_dev, size_t 
  * kernel really runs on.) */
 int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, float* ms_total);
 
-/* Small batches: lean launches (revolute chain of up to 7 joints, identity tool, unit weights, goal + integer-order
- * decay repellers, no module flag, qdot_out / status only) of batches up to max_batch arms take a kernel that
- * spreads each arm over eight lanes (BASELINE north_star's "wavefront per arm" mapping) instead
- * of one lane per arm.  Default 4096, the measured crossover (profiles/, tools/ab_mapping.py), or the environment
- * variable VFIK_SUB8_MAX_BATCH when the handle is created; 0 = never.  vfik_small_batch_launches: how many launches
- * took that kernel so far. */
+/* Small batches -- what vfclik itself runs is a handful of arms, each with its vf, nullspace and debug process and the bridge's
+ * mixer (scripts/vfclik:88-105).  Launches the eight-lanes-per-arm kernel serves (revolute chain of up to 7 joints, identity tool,
+ * unit weights, goal + integer-order decay repellers; with or without the nullspace module, joint-limit task, mixer, limiter,
+ * /control; outputs qdot_out, qdot_vf, qdot_null, pose, pose_nt, qdist, status; no gate, no per-arm limits or weights) take it
+ * instead of one lane per arm up to the batch size where the same-box A/B stops winning (profiles/r03_latency_small_*.txt;
+ * DESIGN.md section 5.8): 4096 arms when the per-cycle rows are published or without the nullspace module, 32 arms with the module
+ * and qdot_out alone.  vfik_set_small_batch_kernel sets ONE threshold for all three cases (0 = never; the environment variable
+ * VFIK_SUB8_MAX_BATCH does the same when the handle is created).  vfik_small_batch_launches: how many launches took that kernel
+ * so far. */
 int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch);
 long vfik_small_batch_launches(vfik_handle* h);
 

@@ -1,15 +1,19 @@
 #!/usr/bin/env python
 """Digest of tools/profile_round.sh's output:  python tools/profile_digest.py gpurun_out/<tag> <round>
-Prints a markdown summary and rewrites profiles/pmc_traffic.json (HBM bytes per launch, gfx950 correction applied)."""
+Prints a markdown summary, copies the kernel-statistics CSVs to profiles/r<round>_kernel_stats_{warm,cold}_<W>.csv and rewrites
+profiles/pmc_traffic.json (HBM bytes per launch, gfx950 correction applied)."""
 import csv
 import glob
 import json
 import os
+import re
+import shutil
 import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALG = {"C2": 512 * 4096, "C3": 384 * 65536, "C3N": 384 * 65536, "C5": 696 * 65536}
+ALG = {"C2": 512 * 4096, "C3": 384 * 65536, "C3N": 384 * 65536, "C5": 696 * 65536, "C3F": 600 * 65536, "C5F": 996 * 65536}
+WAVES = {"C2": 4096 // 8, "C3": 1024, "C3N": 1024, "C5": 1024, "C3F": 1024, "C5F": 1024}
 
 
 def one(pattern):
@@ -17,28 +21,48 @@ def one(pattern):
     return f[0] if f else None
 
 
+def kernel_of(name):
+    """`void vfik::(anonymous namespace)::cycle_kernel<float, 7, ...>(vfik::KArgs)` -> `cycle_kernel<float, 7, ...>`"""
+    m = re.search(r"(cycle_\w+<[^>]*>)", name)
+    return m.group(1) if m else name
+
+
+def line_of(path):
+    try:
+        return json.loads(open(path).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def main():
     d, rnd = sys.argv[1], int(sys.argv[2])
-    print("| workload | kernel | dispatches | mean ns (rocprofv3) | median | min | bench line under rocprofv3: us/launch (HIP events) | frac from the CSV | frac the line prints | un-profiled us/launch | un-profiled frac |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
-    for w in ("C2", "C3", "C3N", "C5"):
-        st = one(os.path.join(d, "trace_" + w, "*", "*kernel_stats.csv"))
-        tr = one(os.path.join(d, "trace_" + w, "*", "*kernel_trace.csv"))
-        if not st:
-            continue
-        row = [r for r in csv.DictReader(open(st)) if "::cycle_" in r["Name"]][0]
-        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr)) if "::cycle_" in r["Kernel_Name"]]
-        line = json.loads(open(os.path.join(d, "bench_under_rocprof_%s.json" % w)).read().strip().splitlines()[-1])
-        plain = json.loads(open(os.path.join(d, "bench_%s.json" % w)).read().strip().splitlines()[-1])
-        mean = float(row["AverageNs"])
-        frac_csv = ALG[w] / (mean * 1e-9) / 1e9 / 8000.0
-        print("| %s | `%s` | %s | %.0f | %.0f | %s | %.3f | %.3f | %.3f | %.3f | %.3f |" % (
-            w, row["Name"].split("::")[-1].replace("(vfik::KArgs)", ""), row["Calls"], mean, statistics.median(dur), row["MinNs"],
-            line["roofline"]["us_per_launch_hip_events"], frac_csv, line["roofline"]["frac"],
-            plain["roofline"]["us_per_launch_hip_events"], plain["roofline"]["frac"]))
+    print("| workload | state | kernel | dispatches | rocprofv3 mean ns | median | min | frac from the CSV mean | the traced process's own HIP events, us | plain run (no tracer): us per launch, frac |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for w in ("C2", "C3", "C3N", "C5", "C3F", "C5F"):
+        plain = line_of(os.path.join(d, "bench_%s.json" % w))
+        for state, tdir, under in (("warm", "trace_", "bench_under_rocprof_%s.json"), ("cold", "cold_trace_", "bench_cold_under_rocprof_%s.json")):
+            st = one(os.path.join(d, tdir + w, "*", "*kernel_stats.csv"))
+            tr = one(os.path.join(d, tdir + w, "*", "*kernel_trace.csv"))
+            if not st:
+                continue
+            shutil.copy(st, os.path.join(ROOT, "profiles", "r%02d_kernel_stats_%s_%s.csv" % (rnd, state, w)))
+            row = [r for r in csv.DictReader(open(st)) if "::cycle_" in r["Name"]][0]
+            dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr)) if "::cycle_" in r["Kernel_Name"]]
+            line = line_of(os.path.join(d, under % w))
+            mean = float(row["AverageNs"])
+            frac_csv = ALG[w] / (mean * 1e-9) / 1e9 / 8000.0
+            if plain:
+                pr = plain["roofline"] if state == "warm" else plain["roofline"].get("cold", {})
+                pus = pr.get("us_per_launch_hip_events", pr.get("us_per_launch"))
+                ptxt = "%.3f, %.3f" % (pus, pr["frac"]) if pus else "-"
+            else:
+                ptxt = "-"
+            print("| %s | %s | `%s` | %s | %.0f | %.0f | %s | **%.3f** | %s | %s |" % (
+                w, state, kernel_of(row["Name"]), row["Calls"], mean, statistics.median(dur), row["MinNs"], frac_csv,
+                "%.3f" % line["roofline"]["us_per_launch_hip_events"] if line else "-", ptxt))
     traffic = {}
     print()
-    for w in ("C3", "C3N", "C5"):
+    for w in ("C3", "C3N", "C5", "C3F", "C5F"):
         per = {}
         kname = None
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -58,7 +82,8 @@ def main():
         hbm = fetch * 1024 * 2 + write * 1024
         traffic[w] = {"hbm_bytes_per_launch": hbm, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
                       "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane coalesced stream: doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-                      "dispatches_sampled": len(per["FETCH_SIZE"]), "kernel": kname.split("::")[-1].replace("(vfik::KArgs)", ""), "round": rnd,
+                      "state": "cold (rotating input sets: the launches' inputs come from HBM)",
+                      "dispatches_sampled": len(per["FETCH_SIZE"]), "kernel": kernel_of(kname), "round": rnd,
                       "algorithmic_bytes_per_launch": ALG[w]}
         print("%s: FETCH_SIZE %.1f KB x2 = %.2f MB, WRITE_SIZE %.1f KB = %.2f MB -> %.2f MB per launch vs %.2f MB algorithmic (ratio %.3f)"
               % (w, fetch, fetch * 2048 / 1e6, write, write * 1024 / 1e6, hbm / 1e6, ALG[w] / 1e6, hbm / ALG[w]))
@@ -66,7 +91,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     print()
-    for w in ("C3", "C3N", "C5"):
+    for w in ("C2", "C3", "C3N", "C5", "C3F", "C5F"):
         f = one(os.path.join(d, "pmc_sq_" + w, "*", "*counter_collection.csv"))
         if not f:
             continue
@@ -76,8 +101,8 @@ def main():
                 continue
             per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-        print("%s per wave (1024 waves), median over %d dispatches: " % (w, len(next(iter(per.values())))) +
-              ", ".join("%s %.0f" % (k, statistics.median(v.values()) / 1024.0) for k, v in sorted(per.items())))
+        print("%s per wave (%d waves), median over %d dispatches: " % (w, WAVES[w], len(next(iter(per.values())))) +
+              ", ".join("%s %.0f" % (k, statistics.median(v.values()) / WAVES[w]) for k, v in sorted(per.items())))
 
 
 if __name__ == "__main__":

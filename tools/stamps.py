@@ -19,6 +19,7 @@ robot, B, nobs, io, flags = {"C3": ("lwr", 65536, 8, np.float32, 0), "C5": ("lwr
                              "C2": ("lwr", 4096, 4, np.float64, 0), "C3N": ("lwr", 65536, 8, np.float32, 5),
                              "C3G": ("lwr", 65536, 8, np.float32, 0), "GAN": ("lwr", 65536, 5, np.float32, 0),
                              "C3D": ("lwr", 65536, 8, np.float64, 0),
+                             "C3x2": ("lwr", 131072, 8, np.float32, 0),   # two waves per SIMD's worth of arms: the launch runs in rounds
                              # the full-output cycle (bench.py C3F / C5F): everything vf / nullspace / debug publish
                              "C3F": ("lwr", 65536, 8, np.float32, 5), "C5F": ("lwr_dual14", 65536, 16, np.float32, 7),
                              # ... and single extra outputs, to price them one by one

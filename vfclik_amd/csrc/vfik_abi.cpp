@@ -55,7 +55,8 @@ struct vfik_handle {
     // VFIK_SUB8_MAX_BATCH).  Measured crossover (tools/ab_mapping.py, float64 I/O, goal + 4 repellers): 3-7 % faster than
     // one lane per arm up to 4 096 arms, equal at 8 192, 1.4x / 2.0x / 2.8x SLOWER at 16 384 / 32 768 / 65 536.
     int sub8_max_batch = 4096;
-    int sub8_max_batch_full = 4096;  // the same for launches that publish more than qdot_out (set together by vfik_set_small_batch_kernel)
+    int sub8_max_batch_ns = 32;      // with the nullspace module and qdot_out only: a handful of arms (-7 ... -11 %), even from 64 on
+    int sub8_max_batch_full = 4096;  // launches that publish the per-cycle rows: -18 ... -22 % at every size (vfik_set_small_batch_kernel sets all three)
     long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
     int n_simd = 1024;       // 4 per CU of this device
     // Batches beyond one wave per SIMD may take the persistent launch (cycle_kernel PERS; VFIK_PERSISTENT=1).  Off by default:
@@ -105,6 +106,7 @@ struct vfik_handle {
     void* arena_host = nullptr;
     size_t arena_bytes = 0;
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
+    Scratch sc[20];  // ... and per-member device buffers for calls of more than 1 MiB
     // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
     // its own device staging buffers and events; s_in / s_out are the side streams
     static constexpr int PIPE = 3;
@@ -242,6 +244,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.q_ref_out = io->q_ref ? io->q_ref_out : nullptr;
     a.sub8_max_batch = h->sub8_max_batch;
     a.sub8_max_batch_full = h->sub8_max_batch_full;
+    a.sub8_max_batch_ns = h->sub8_max_batch_ns;
     a.n_simd = h->n_simd;
     a.pers = h->pers;
     a.stamps = h->d_stamps;
@@ -324,7 +327,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         int b = std::atoi(e);
         if (b == 64 || b == 128 || b == 192 || b == 256) h->block = b;  // tuning knob; LDS per block = waves x 27-56 KB
     }
-    if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = h->sub8_max_batch_full = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = h->sub8_max_batch_full = h->sub8_max_batch_ns = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
@@ -373,6 +376,7 @@ void vfik_destroy(vfik_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->arena_dev) (void)hipFree(h->arena_dev);
     if (h->arena_host) (void)hipHostFree(h->arena_host);
+    for (auto& sc : h->sc) if (sc.p) (void)hipFree(sc.p);
     for (auto& ps : h->pipe) {
         if (ps.ev_out) (void)hipEventSynchronize(ps.ev_out);
         for (auto& s : ps.sc) if (s.p) (void)hipFree(s.p);
@@ -803,8 +807,8 @@ void device_io(void* const* din, void* const* dout, vfik_io& d) {
 }
 }  // namespace
 
-// Host-pointer form: ONE copy in, the launches, ONE copy out, one synchronisation.  Inputs and outputs live in one device
-// arena and one pinned host arena (same layout, every member 256-byte aligned); the caller's arrays are packed into /
+// Host-pointer form, calls of up to 1 MiB in all: ONE copy in, the launches, ONE copy out, one synchronisation.  Inputs and
+// outputs live in one device arena and one pinned host arena (same layout, every member 256-byte aligned); the caller's arrays are packed into /
 // unpacked from the pinned arena on the host.  (Until round 3 every member was its own hipMemcpyAsync: with the eleven
 // outputs the port-level host layer asks for that was 197 us per call for ONE arm, ~15 us per copy, against 34 us for
 // qdot_out alone.)
@@ -818,6 +822,42 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
     for (int i = 0; i < N_HIN; ++i) { off_in[i] = total; if (x.hin[i]) total += up(x.bin[i]); }
     const size_t in_bytes = total;
     for (int i = 0; i < N_HOUT; ++i) { off_out[i] = total; if (x.hout[i]) total += up(x.bout[i]); }
+    if (total > ((size_t)1 << 20)) {
+        // Large batches: the copies are bandwidth, not count -- every member straight between the caller's array and its own
+        // device buffer (through the arena a C3 step paid a host memcpy of 1.8 MB each way: 236 us instead of 142).
+        auto need = [&](int i, size_t bytes) -> void* {
+            auto& sc = h->sc[i];
+            if (sc.bytes < bytes) {
+                if (sc.p) (void)hipFree(sc.p);
+                sc.p = nullptr; sc.bytes = 0;
+                if (hipMalloc(&sc.p, bytes) != hipSuccess) return nullptr;
+                sc.bytes = bytes;
+            }
+            return sc.p;
+        };
+        void* din[N_HIN] = {};
+        for (int i = 0; i < N_HIN; ++i)
+            if (x.hin[i]) {
+                din[i] = need(i, x.bin[i]);
+                if (!din[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+                HIP_TRY(hipMemcpyAsync(din[i], x.hin[i], x.bin[i], hipMemcpyHostToDevice, h->stream));
+            }
+        void* dout[N_HOUT];
+        for (int i = 0; i < N_HOUT; ++i) {
+            dout[i] = x.hout[i] ? need(N_HIN + i, x.bout[i]) : nullptr;
+            if (x.hout[i] && !dout[i]) return fail(VFIK_E_HIP, "scratch allocation failed");
+            // gated arms store nothing: their rows of the caller's arrays must come back as they went in
+            if (x.hout[i] && io->active) HIP_TRY(hipMemcpyAsync(dout[i], x.hout[i], x.bout[i], hipMemcpyHostToDevice, h->stream));
+        }
+        vfik_io d;
+        device_io(din, dout, d);
+        const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
+        if (rc != VFIK_OK) return rc;
+        for (int i = 0; i < N_HOUT; ++i)
+            if (x.hout[i]) HIP_TRY(hipMemcpyAsync(x.hout[i], dout[i], x.bout[i], hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return VFIK_OK;
+    }
     if (h->arena_bytes < total) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->arena_dev) (void)hipFree(h->arena_dev);
@@ -1130,6 +1170,7 @@ int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {
     if (max_batch < 0) return fail(VFIK_E_ARG, "max_batch must be >= 0");
     h->sub8_max_batch = max_batch;
     h->sub8_max_batch_full = max_batch;
+    h->sub8_max_batch_ns = max_batch;
     return VFIK_OK;
 }
 

@@ -118,7 +118,8 @@ struct KArgs {
     const void* q_hi;            //        the chain's static limits of KConst
     void* q_ref_out;             // [B][n] the joint controller's reference after its clamp (joint_p_controller:121), or NULL
     int sub8_max_batch;          // batches up to this size take the eight-lanes-per-arm kernel when the launch is lean (0: never)
-    int sub8_max_batch_full;     // ... when the launch asks for more than qdot_out (the outputs the per-arm processes publish)
+    int sub8_max_batch_ns;       // ... with the nullspace module, qdot_out / status only
+    int sub8_max_batch_full;     // ... when the launch asks for more than qdot_out (the rows the per-arm processes publish every cycle)
     int n_simd;                  // SIMDs of the device (4 per CU): launches of at most that many waves are one wave per SIMD
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
 };

@@ -2355,8 +2355,13 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
         const bool served = fastf && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
                             !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
-                            (NS || (a.flags == 0 && !a.null_control)) && a.B <= (lean ? a.sub8_max_batch : a.sub8_max_batch_full);
-        if (served) {
+                            (NS || (a.flags == 0 && !a.null_control));
+        // Adopted where the same-box A/B wins (profiles/r03_latency_small_*.txt, 1 ... 4 096 arms): launches that publish the
+        // per-cycle rows (pose, pose_no_tool, qdotOut, qdotout, qdist) -18 ... -22 % at every size; qdot_out alone without the
+        // nullspace module -4 ... -20 %; qdot_out alone WITH it -7 ... -11 % for a handful of arms, +-3 % from 64 arms on.
+        const bool rows = a.qdot_vf || a.qdot_null || a.pose || a.pose_nt || a.qdist;
+        const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
+        if (served && a.B <= cap) {
             const dim3 g8((a.B + 7) / 8), b8(64);
             hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
             if (sub8) *sub8 = 1;
