@@ -71,6 +71,7 @@ struct vfik_handle {
     bool chain_set = false;
     vfik_params params{};
     // device state
+    void* d_arena = nullptr;   // [goal | kconst | lastvec | slots_fast | slots]: d_goal, d_kconst, d_lastvec, d_slots_fast, d_slots point into it
     void* d_goal = nullptr;    // 4 quad planes
     void* d_slots = nullptr;   // 2*S quad planes
     void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
@@ -246,6 +247,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.sub8_max_batch_full = h->sub8_max_batch_full;
     a.sub8_max_batch_ns = h->sub8_max_batch_ns;
     a.n_simd = h->n_simd;
+    a.arena = h->d_arena;
     a.pers = h->pers;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
@@ -339,12 +341,21 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     const size_t B = batch;
     h->Bpad = (batch + 63) / 64 * 64;
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
-    if (dev_alloc(h, &h->d_goal, 4 * quad_plane, true)) return bail("alloc goal");
-    if (dev_alloc(h, &h->d_slots, std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane, true)) return bail("alloc slots");  // >= 1 slot: the prefetch reads slot 0
-    if (dev_alloc(h, &h->d_slots_fast, (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane, true)) return bail("alloc compact slots");
-    if (dev_alloc(h, (void**)&h->d_lastvec, (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float), true)) return bail("alloc lastvec");
+    {   // the state a lean launch reads, in one allocation whose layout the kernel can derive (vfik_kernel.h: arena layout)
+        const size_t sz_goal = 4 * quad_plane;
+        const size_t sz_kc = VFIK_KCONST_SLOT(vfik::kconst_bytes(n_joints));   // (+ slack inside: the kinematics block is copied in whole 1-KiB rows)
+        const size_t sz_lv = (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float);
+        const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
+        const size_t sz_sl = std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane;  // >= 1 slot: the prefetch reads slot 0
+        if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_sl, true)) return bail("alloc state arena");
+        char* a0 = static_cast<char*>(h->d_arena);
+        h->d_goal = a0;
+        h->d_kconst = a0 + sz_goal;
+        h->d_lastvec = reinterpret_cast<float*>(a0 + sz_goal + sz_kc);
+        h->d_slots_fast = a0 + sz_goal + sz_kc + sz_lv;
+        h->d_slots = a0 + sz_goal + sz_kc + sz_lv + sz_sf;
+    }
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
-    if (dev_alloc(h, &h->d_kconst, vfik::kconst_bytes(n_joints) + 2048, true)) return bail("alloc kconst");  // + slack: the kinematics block is copied in whole 1-KiB rows
     h->slots_per_arm.assign(B, 0);
     h->arm_order.assign(B, -1);
 #ifdef VFIK_STAMPS
@@ -372,7 +383,7 @@ void vfik_destroy(vfik_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_goal, h->d_slots, h->d_slots_fast, h->d_tool, h->d_ext, h->d_lastvec, h->d_mixw, h->d_kconst, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1], h->d_objects, h->d_obs_pose, h->d_obs_v6};
+    void* ptrs[] = {h->d_arena, h->d_tool, h->d_ext, h->d_mixw, h->d_stamps, h->d_mixw_arm, h->d_track, h->d_wts, h->d_rollq[0], h->d_rollq[1], h->d_objects, h->d_obs_pose, h->d_obs_v6};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->arena_dev) (void)hipFree(h->arena_dev);
     if (h->arena_host) (void)hipHostFree(h->arena_host);

@@ -121,7 +121,24 @@ struct KArgs {
     int sub8_max_batch_ns;       // ... with the nullspace module, qdot_out / status only
     int sub8_max_batch_full;     // ... when the launch asks for more than qdot_out (the rows the per-arm processes publish every cycle)
     int n_simd;                  // SIMDs of the device (4 per CU): launches of at most that many waves are one wave per SIMD
+    const void* arena;           // the handle's state arena [goal | kconst | lastvec | slots_fast | slots] (arena_layout), or NULL
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
+};
+
+// The per-handle device state a LEAN launch reads lives in ONE allocation with offsets that follow from (io type, joints, Bpad):
+//   [goal: 4 quad planes | kconst: KCONST_SLOT(nj) bytes | lastvec: (nj + 4) / 4 planes of 16 B | slots_fast ... | slots ...]
+// so that such a launch's kernarg is one base pointer + the io pointers (KLean, 56 bytes) instead of the 340-byte KArgs: what a
+// launch costs the HOST grows with its kernarg (tools/ubench_launch: 32-64 B 2.8 us, 336 B 3.9 us on a slow host), and at a
+// 5-us launch period the enqueue loop is never far from being the bottleneck.
+#define VFIK_KCONST_SLOT(kconst_bytes) ((((kconst_bytes) + 2048) + 255) / 256 * 256)
+struct KLean {
+    const void* base;            // the arena
+    const void* q;
+    void* qdot_out;
+    int* status;
+    int B, Bpad, slots_used, fast_order;
+    unsigned flags;
+    int block;
 };
 
 // size of KConst<nj> for the host (0 if nj is not built); kconst_fill returns the largest

@@ -749,10 +749,37 @@ template <typename T> struct SlotLds {
 // region (they are issued between the joints of the kinematics, where the first chunk's slot requests go).  Launched in
 // rounds of one wave per SIMD instead, 131 072 arms cost 2.33 x the 65 536-arm launch: every round pays its own request
 // phase, q round trip and tail.
+// Lean single-cycle launches on the straight-line path take the 56-byte KLean instead of the 340-byte KArgs (vfik_kernel.h): the
+// handle's state is one arena whose layout follows from (io type, joints, Bpad).  (The diagnostic stamps build keeps KArgs.)
+#ifdef VFIK_STAMPS
+template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = false; };
+#else
+template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = LEAN == 1 && !ROLL && FASTF; };
+#endif
+template <typename T, int NJ> struct ArenaLayout {
+    __host__ __device__ static long kconst_off(long Bpad) { return 4 * Bpad * 4 * (long)sizeof(T); }
+    __host__ __device__ static long lastvec_off(long Bpad) { return kconst_off(Bpad) + VFIK_KCONST_SLOT(KTab<NJ>::OFFSET + 1024); }
+    __host__ __device__ static long slots_fast_off(long Bpad) { return lastvec_off(Bpad) + (long)((NJ + 4) / 4) * Bpad * 16; }
+};
+
 template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) cycle_kernel(const KArgs a_in) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7), "PERS: lean straight-line float launches only");
-    KArgs a = a_in;
+    KArgs a;
+    if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
+        a = KArgs{};
+        a.B = a_in.B; a.Bpad = a_in.Bpad; a.slots_used = a_in.slots_used; a.fast_order = a_in.fast_order; a.flags = a_in.flags; a.block = a_in.block;
+        a.q = a_in.q; a.qdot_out = a_in.qdot_out; a.status = a_in.status;
+        const char* const base = static_cast<const char*>(a_in.base);
+        a.goal = base;
+        a.kc = base + ArenaLayout<T, NJ>::kconst_off(a_in.Bpad);
+        a.lastvec = reinterpret_cast<float*>(const_cast<char*>(base) + ArenaLayout<T, NJ>::lastvec_off(a_in.Bpad));
+        a.slots_fast = base + ArenaLayout<T, NJ>::slots_fast_off(a_in.Bpad);
+        a.slots = a.slots_fast;  // (never read on the straight-line path)
+    } else {
+        a = a_in;
+    }
     if constexpr (CF >= 0) a.flags = (unsigned)CF;
     if constexpr (LEAN != 0) {  // 1: lean, 2: lean with q_out kept (one cycle of a stepped rollout, long chains)
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags are run-time unless CF fixes them)
@@ -2321,6 +2348,19 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
     }
 }
 
+// The argument block a kernel variant takes: KLean for the lean single-cycle straight-line variants, KArgs otherwise
+template <int LEAN, bool ROLL, bool FASTF>
+typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type args_for(const KArgs& a) {
+    if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
+        KLean k;
+        k.base = a.arena; k.q = a.q; k.qdot_out = a.qdot_out; k.status = a.status;
+        k.B = a.B; k.Bpad = a.Bpad; k.slots_used = a.slots_used; k.fast_order = a.fast_order; k.flags = a.flags; k.block = a.block;
+        return k;
+    } else {
+        return a;
+    }
+}
+
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, int* sub8) {
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
@@ -2376,7 +2416,7 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         if (lean && !a.q_out && a.n_cycles == 0 && a.pers && nchunks > (long)a.n_simd) {
             const dim3 gp((unsigned)a.n_simd), bp(64);
             const size_t lds_p = Stage<T>::lean_bytes(NJ) + Stage<T>::kin_off(NJ);
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, true>), gp, bp, lds_p, stream, a);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, true>), gp, bp, lds_p, stream, args_for<1, false, true>(a));
             return;
         }
     }
@@ -2387,15 +2427,15 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
             if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds_lean, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds_lean, stream, a);
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
                     return;
                 }
             }
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds_lean, stream, a);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
             return;
         }
         if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
