@@ -161,8 +161,9 @@ def kernel_name(io_name, n, flags, batch, sub8, full=False):
     t = "float" if io_name == "float32" else "double"
     if sub8:
         return "vfik::cycle_sub8_kernel<%s,%d>" % (t, n)
-    if full:  # optional outputs asked for: the variant with run-time options
-        return "vfik::cycle_kernel<%s,%d,%s,true,false,true,0,-1>" % (t, n, "true" if flags & 1 else "false")
+    if full:  # the per-cycle rows asked for, no per-arm option: the publishing lean variant (LEAN 3)
+        cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
+        return "vfik::cycle_kernel<%s,%d,%s,true,false,true,3,%d>" % (t, n, "true" if flags & 1 else "false", cf)
     cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
     return "vfik::cycle_kernel<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
 

@@ -107,7 +107,7 @@ struct vfik_handle {
     void* arena_host = nullptr;
     size_t arena_bytes = 0;
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
-    Scratch sc[20];  // ... and per-member device buffers for calls of more than 1 MiB
+    Scratch sc[20];  // ... and per-member device buffers for calls of few large members
     // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
     // its own device staging buffers and events; s_in / s_out are the side streams
     static constexpr int PIPE = 3;
@@ -818,7 +818,7 @@ void device_io(void* const* din, void* const* dout, vfik_io& d) {
 }
 }  // namespace
 
-// Host-pointer form, calls of up to 1 MiB in all: ONE copy in, the launches, ONE copy out, one synchronisation.  Inputs and
+// Host-pointer form, calls whose bytes are small against their member count: ONE copy in, the launches, ONE copy out, one synchronisation.  Inputs and
 // outputs live in one device arena and one pinned host arena (same layout, every member 256-byte aligned); the caller's arrays are packed into /
 // unpacked from the pinned arena on the host.  (Until round 3 every member was its own hipMemcpyAsync: with the eleven
 // outputs the port-level host layer asks for that was 197 us per call for ONE arm, ~15 us per copy, against 34 us for
@@ -833,9 +833,14 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
     for (int i = 0; i < N_HIN; ++i) { off_in[i] = total; if (x.hin[i]) total += up(x.bin[i]); }
     const size_t in_bytes = total;
     for (int i = 0; i < N_HOUT; ++i) { off_out[i] = total; if (x.hout[i]) total += up(x.bout[i]); }
-    if (total > ((size_t)1 << 20)) {
-        // Large batches: the copies are bandwidth, not count -- every member straight between the caller's array and its own
-        // device buffer (through the arena a C3 step paid a host memcpy of 1.8 MB each way: 236 us instead of 142).
+    int members = 0;
+    for (int i = 0; i < N_HIN; ++i) members += x.hin[i] != nullptr;
+    for (int i = 0; i < N_HOUT; ++i) members += x.hout[i] != nullptr;
+    // The arena saves ~15 us per member beyond two and costs a host memcpy of every byte (~38 GB/s): measured 197 -> 40 us for
+    // one arm with 13 members, 306 -> 190 us for 4 096 arms (2 MB), but 142 -> 236 us for a C3 step (q and qdot_out, 3.6 MB).
+    if (total > ((size_t)256 << 10) && total > (size_t)std::max(0, members - 2) * ((size_t)512 << 10)) {
+        // Few large members: the copies are bandwidth, not count -- every member straight between the caller's array and its
+        // own device buffer.
         auto need = [&](int i, size_t bytes) -> void* {
             auto& sc = h->sc[i];
             if (sc.bytes < bytes) {

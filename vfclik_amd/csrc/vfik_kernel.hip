@@ -781,12 +781,20 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         a = a_in;
     }
     if constexpr (CF >= 0) a.flags = (unsigned)CF;
-    if constexpr (LEAN != 0) {  // 1: lean, 2: lean with q_out kept (one cycle of a stepped rollout, long chains)
+    // LEAN: 1 = lean, 2 = lean with q_out kept (one cycle of a stepped rollout, long chains), 3 = PUBLISHING lean: no per-arm
+    // option either, but the rows the per-arm processes publish (qdot_vf, qdot_null, pose, pose_nt, v6, qdist, goal_dist),
+    // /control and the fresh-q gate stay run-time -- what ControlCycleBatch's default cycle and an array caller that wants
+    // the poses ask for.  The fully general variant (LEAN 0) costs such a launch ~1 700 cycles a wave in options it does not use.
+    if constexpr (LEAN != 0) {
         if constexpr (!NULLSP) a.flags = 0;  // (with the nullspace module the flags are run-time unless CF fixes them)
-        a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.null_control = nullptr; a.ext = nullptr;
-        a.q_ref = nullptr; a.q_cmded = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
-        a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr;
-        a.active = nullptr; a.q_lo = nullptr; a.q_hi = nullptr; a.q_ref_out = nullptr;
+        a.tool_stride = 0; a.mixw = nullptr; a.wts = nullptr; a.ext = nullptr;
+        a.q_ref = nullptr; a.q_cmded = nullptr; a.q_lo = nullptr; a.q_hi = nullptr; a.q_ref_out = nullptr;
+        if constexpr (LEAN != 3) {
+            a.null_control = nullptr; a.qdot_vf = nullptr; a.qdot_null = nullptr; a.pose = nullptr; a.pose_nt = nullptr;
+            a.v6 = nullptr; a.qdist = nullptr; a.goal_dist = nullptr; a.active = nullptr;
+        } else {
+            a.status_or = 0; a.q_out = nullptr;
+        }
         if constexpr (LEAN == 1) a.status_or = 0;  // (a stepped rollout accumulates the status bits of its cycles)
         if constexpr (!ROLL && LEAN == 1) a.q_out = nullptr;  // (a rollout's q_out is its result)
     }
@@ -1722,7 +1730,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         // goal block's rows, dead by now) and written with 16 bytes per lane, 1 KiB per instruction.  Not for LEAN launches
         // (seven stores in all), gated launches (a silent arm's row must stay), the batch's last partial wave, or output
         // pointers that are not 16-byte aligned: those store lane by lane.
-        const bool tiles = LEAN == 0 && !a.active && (arm - lanec) + 64 <= a.B;
+        const bool tiles = (LEAN == 0 || LEAN == 3) && !a.active && (arm - lanec) + 64 <= a.B;
         auto put_rows = [&](void* out, auto kconst, auto&& val) {   // out[arm][i] = val(i), i < K
             constexpr int K = decltype(kconst)::value;
             T* const o = static_cast<T*>(out);
@@ -2443,6 +2451,26 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
                 hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds_lean, stream, a);
                 return;
             }
+        }
+    }
+    if constexpr (PL) {
+        // publishing lean launches (LEAN 3): the straight-line path, no per-arm option, single cycle
+        const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
+                           !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
+        if (lean3) {
+            if constexpr (NS && NJ <= 7) {
+                constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
+                if (a.flags == (unsigned)NSMIX) {
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, NSMIX>), grid, blk, lds_lean, stream, a);
+                    return;
+                }
+                if (a.flags == (unsigned)NSJLMIX) {
+                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, NSJLMIX>), grid, blk, lds_lean, stream, a);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3>), grid, blk, lds_lean, stream, a);
+            return;
         }
     }
     if constexpr (PL) {
