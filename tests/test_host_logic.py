@@ -218,3 +218,19 @@ def test_tracking_state_majority_vote():
     for k in range(25):   # arrived
         msgs += ts.update(0.001, 0.2, 0.5, 0.5)
     assert msgs == [("xyz", "on goal"), ("rot", "on goal")]
+
+
+def test_profile_digest_parses_kernel_names():
+    """profiles/pmc_traffic.json said "kernel": "KArgs)" -- the name was cut at the last '::'."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("profile_digest", os.path.join(root, "tools", "profile_digest.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    n1 = "void vfik::(anonymous namespace)::cycle_kernel<float, 7, false, true, false, true, 1, -1, false>(std::conditional<SmallArgs<1, false, true>::value, vfik::KLean, vfik::KArgs>::type)"
+    assert m.kernel_of(n1) == "cycle_kernel<float, 7, false, true, false, true, 1, -1, false>"
+    assert m.kernel_of("void vfik::(anonymous namespace)::cycle_sub8_kernel<double, 7, true>(vfik::KArgs)") == "cycle_sub8_kernel<double, 7, true>"
+    import json
+    t = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert all(v["kernel"].startswith("cycle_") for v in t.values())
