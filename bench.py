@@ -200,6 +200,10 @@ def parse_args(argv=None):
     ap.add_argument("--state", default="both", choices=["both", "warm", "cold"],
                     help="both: `value` and `roofline` from back-to-back launches of ONE input set (cache-resident), `roofline.cold` from the "
                          "rotating sets; cold: every launch of the run rotates (what a rocprofv3 trace of the cold state needs); warm: no rotation")
+    ap.add_argument("--launch", default="auto", choices=["auto", "direct", "graph"],
+                    help="how the K launches of a timed region reach the GPU: direct = K vfik_step calls; graph = one replay of a hipGraph that "
+                         "captured those K vfik_step calls (the host then costs ~0.3 us per launch instead of 3-5); auto = whichever the warm-up "
+                         "measures faster on this box (graph only when it wins by > 3 %: it pays when the enqueue loop, not the GPU, sets the pace)")
     ap.add_argument("--dump-reps", default=None, help="diagnostic: write the per-repetition times (us per launch, HIP events) to this file")
     ap.add_argument("--sync-each", action="store_true",
                     help="diagnostic: synchronize after every launch (un-overlapped kernel durations for a rocprofv3 kernel trace); "
@@ -268,7 +272,9 @@ def worker(args):
     tdt = torch.float32 if io_dtype == np.float32 else torch.float64
     dev = torch.device("cuda", local_rank)
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the timing reductions run
-    stream = torch.cuda.current_stream()
+    # the launch stream: a stream of its own (not the legacy default stream), so that the K launches of a region can also be captured into a hipGraph
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     out_cols = {"pose": 16, "pose_nt": 16, "qdot_vf": chain.n, "qdot_null": chain.n, "qdist": chain.n}
 
     sharded = []
@@ -327,7 +333,18 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.cpu()]
 
-    def timed(active_sets, K, R, wall=True):
+    def capture(active_sets, K):
+        """The K launches of a region as ONE hipGraph (torch.cuda.CUDAGraph captures the vfik_step calls on the launch stream)."""
+        ns = len(active_sets)
+        steppers = [e_i.stepper(io_i) for e_i, io_i in active_sets]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for i in range(K):
+                steppers[i % ns]()
+        torch.cuda.synchronize()
+        return g
+
+    def timed(active_sets, K, R, wall=True, graph=None):
         """R repetitions of the timed region; returns (wall seconds per WALL repetition, enqueue seconds, HIP-event ms per EVENT
         repetition).  Repetitions alternate between two kinds: WALL repetitions (even) carry nothing but the K launches between
         the stamps and give `value`; EVENT repetitions (odd) bracket the same K launches with HIP events on the launch stream
@@ -348,7 +365,9 @@ def worker(args):
             t0 = time.perf_counter()
             if with_events:
                 ev0.record(stream)
-            if args.sync_each:
+            if graph is not None:
+                graph.replay()
+            elif args.sync_each:
                 for step in steps:
                     step()
                     torch.cuda.synchronize()
@@ -373,7 +392,28 @@ def worker(args):
         e_i, io_i = primary[i % len(primary)]
         e_i.step(io_i)
     torch.cuda.synchronize()
-    wall_s, enqueue_s, ev_ms = timed(primary, K, R)
+    # direct launches or a captured graph of them: decided in the (untimed) warm-up, per --launch
+    graph, launch_note = None, "direct: K vfik_step calls per region"
+    if args.launch != "direct" and not args.sync_each:
+        try:
+            g = capture(primary, K)
+            if args.launch == "graph":
+                graph = g
+            else:
+                d_s, _, _ = timed(primary, K, 5)
+                g_s, _, _ = timed(primary, K, 5, graph=g)
+                picks = reduce_max([pctl(d_s, 50), pctl(g_s, 50)])   # every rank takes the same decision: on the slowest rank's times
+                if picks[1] < 0.97 * picks[0]:
+                    graph = g
+                launch_note_trial = "warm-up trial, us per step: direct %.3f, graph %.3f" % (picks[0] * 1e6 / K, picks[1] * 1e6 / K)
+            if graph is not None:
+                launch_note = "hipGraph: one replay of K captured vfik_step launches per region"
+            if args.launch == "auto":
+                launch_note += " (auto; " + launch_note_trial + ")"
+        except Exception as e:  # capture not possible on this stack: stay direct, say so
+            graph = None
+            launch_note = "direct (graph capture failed: %s)" % str(e).splitlines()[0][:120]
+    wall_s, enqueue_s, ev_ms = timed(primary, K, R, graph=graph)
     own_wall_s = list(wall_s)
     wall_s = reduce_max(wall_s)        # per repetition: the slowest rank
     per_rank_ms = None
@@ -389,7 +429,13 @@ def worker(args):
         for e_i, io_i in sets:
             e_i.step(io_i)
         torch.cuda.synchronize()
-        _, _, cold_ms = timed(sets, K, R, wall=False)
+        cold_graph = None
+        if graph is not None:
+            try:
+                cold_graph = capture(sets, K)
+            except Exception:
+                cold_graph = None
+        _, _, cold_ms = timed(sets, K, R, wall=False, graph=cold_graph)
         cold_ms = reduce_max(cold_ms)
         cold_us = [m * 1e3 / K for m in cold_ms]
         cu = pctl(cold_us, 50)
@@ -492,7 +538,7 @@ def worker(args):
             "config": {"workload": "%s: batch=%d/GPU x %d-DOF %s, goal + %d decay repellers, %s I/O, flags=0x%x"
                                    % (args.workload, B, chain.n, chain.name, nobs, io_name, flags),
                        "parallelism": "arm batch sharded over %d GPU(s), no collective" % world,
-                       "lambda": params.lambda_, "launches_per_step": 1,
+                       "lambda": params.lambda_, "launches_per_step": 1, "launch": launch_note,
                        "host_enqueue_us_per_step": pctl(enqueue_s, 50) * 1e6 / K},
             "repetitions": {"count": R, "steps_each": K, "value_p10": total / p90_s, "value_median": total / med_s, "value_p90": total / p10_s,
                             "ms_per_step_p10": p10_s * 1e3 / K, "ms_per_step_median": med_s * 1e3 / K, "ms_per_step_p90": p90_s * 1e3 / K,

@@ -73,3 +73,37 @@ def test_pipeline_and_synchronous_path_interleave(env):
     eng.wait(t1)
     assert np.array_equal(o1["qdot_out"], mid["qdot_out"]) and np.array_equal(o2["qdot_out"], mid["qdot_out"])
     eng.close()
+
+
+def test_vfik_step_is_capturable_into_a_hip_graph():
+    """A launch-bound caller that replays fixed device buffers can capture K vfik_step launches into ONE hipGraph (what
+    bench.py --launch graph does): the captured launches give the results of direct launches, replay after replay."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from vfclik_amd import _abi, engine, robots, synth
+    chain = robots.lwr()
+    B = 4096 + 64
+    w = synth.make_workload(chain, B, 3, seed=77, io_dtype=np.float32)
+    for flags in (0, _abi.F_NULLSPACE | _abi.F_MIXER):
+        eng = engine.Engine(chain, B, io_dtype=np.float32, max_slots=4, params=_abi.default_params(flags=flags))
+        eng.set_fields(w["fields"], w["nfields"])
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            eng.use_stream(s.cuda_stream)
+            q = torch.from_numpy(w["q"].astype(np.float32)).cuda()
+            out_d = torch.zeros(B, 7, dtype=torch.float32, device="cuda")
+            out_g = torch.zeros(B, 7, dtype=torch.float32, device="cuda")
+            eng.step(eng.make_io(q, qdot_out=out_d))
+            torch.cuda.synchronize()
+            io_g = eng.make_io(q, qdot_out=out_g)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                for _ in range(5):
+                    eng.step(io_g)
+            for _ in range(3):
+                out_g.zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(out_g, out_d)
+        eng.close()

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-common="--no-cpu-baseline --rollout 0 --host-path 0"
+common="--no-cpu-baseline --rollout 0 --host-path 0 --launch direct"
 for w in $wls; do
   echo "bench both $w"; timeout -k 10 300 python3 $R/bench.py --workload $w $common > $out/bench_both_$w.json 2> $out/bench_both_$w.err || echo "bench both $w failed"
   echo "cold trace $w"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cold_trace_$w -- python3 $R/bench.py --workload $w $common --state cold > $out/bench_cold_under_rocprof_$w.json 2> $out/cold_trace_$w.err || echo "cold trace $w failed"
