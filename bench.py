@@ -338,7 +338,8 @@ def worker(args):
         ns = len(active_sets)
         steppers = [e_i.stepper(io_i) for e_i, io_i in active_sets]
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        # (thread-local capture mode: a collective library's watchdog thread querying its events must not invalidate the capture)
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             for i in range(K):
                 steppers[i % ns]()
         torch.cuda.synchronize()
