@@ -11,7 +11,10 @@
 // with every input of the cycle staged into the wave's LDS region by direct global -> LDS loads.  No
 // cross-lane traffic is needed, no lane idles, and the per-arm field list is read as a structure of
 // arrays so every wave-level load is one contiguous 1-KiB row.  No MFMA: there is no contraction to feed it.
-// Small lean batches (<= 4 096 arms) take cycle_sub8_kernel instead: eight lanes per arm (measured crossover).
+// Small batches (a handful of arms with vfclik's default process set, up to 4 096 arms when the per-cycle rows are published or
+// no module runs) take cycle_sub8_kernel instead: eight lanes per arm, adopted where the same-box A/B wins (launch_v).
+// Kernels of this file: cycle_kernel (variants by template: io type, joints, nullspace module, PLAIN, rollout, field path, LEAN,
+// compile-time flags, persistent), cycle_sub8_kernel, mix_kernel, track_kernel, monitor_kernel, probe_kernel.
 //
 // Arithmetic is float64 whatever the io dtype (DESIGN.md "Precision").
 #include "vfik_kernel.h"
