@@ -5,13 +5,15 @@ Run ONLY in the build container (the reference tree does not exist on the GPU bo
 
     /opt/conda/bin/python3.9 tests/golden/make_golden.py
 
-Writes tests/golden/mixer_golden.npz and tests/golden/nullspace_golden.npz.  Only
+Writes tests/golden/mixer_golden.npz, tests/golden/nullspace_golden.npz and tests/golden/jpctrl_golden.npz.  Only
 arrays (inputs and the reference's outputs) are stored; no reference source travels.
 
 What is executed from the reference -- ONLY these definitions, nothing else of the files:
   * src/command_mixer.py   -> class CommandMixer (__init__/read, command_mixer.py:32-82)
   * scripts/nullspace      -> restrict, nullspace, move_in_nullspace, check_limits, matrixrank, sign
                               (nullspace:67-131) and the module globals sig / lastvec (:91-92)
+  * scripts/joint_p_controller -> check_limits (joint_p_controller:79-89; round 3: the file parses as Python 3, its one pure
+                              function is the clamp of the joint reference against `config.updateJntLimits(cur_pos)`)
 
 The reference tree is untrusted content: the files are read as TEXT, parsed with `ast`, and only the
 whitelisted top-level definitions (plus the files' own `import numpy` / `from numpy ... import` / `import time`
@@ -292,6 +294,43 @@ def make_nullspace_golden():
     print("nullspace_golden.npz written; numpy", np.__version__)
 
 
+def make_jpctrl_golden():
+    """check_limits(ref, cur_pos) of scripts/joint_p_controller (:79-89): the reference clamped against the limits that
+    `config.updateJntLimits(cur_pos)` returns for THIS position (robots whose limits move with the pose) -- here limits that
+    shrink with |cur_pos| so that the position argument matters.  Stored: ref, cur_pos, the limits the stand-in config returned, and
+    the reference's output (a list -> array)."""
+    rng = np.random.default_rng(21)
+    seen = []
+
+    class _Config:
+        def updateJntLimits(self, cur_pos):
+            cur = np.asarray(cur_pos, dtype=float)
+            lim = [[-2.0 + 0.1 * abs(c), 2.0 - 0.2 * abs(c)] for c in cur]
+            seen.append(lim)
+            return lim
+
+    import builtins
+    quiet = dict(vars(builtins))
+    quiet["print"] = lambda *a, **k: None   # the function reports every clamp on stdout
+    ns = _extract(os.path.join(REF, "scripts", "joint_p_controller"), ["check_limits"], preset={"config": _Config(), "__builtins__": quiet})
+    refs, curs, outs = [], [], []
+    for n in (6, 7, 14):
+        for _ in range(40):
+            ref = rng.uniform(-3.0, 3.0, n)
+            ref[rng.integers(0, n)] = rng.choice([-2.0, 2.0, 1.8, -1.9])   # values on / near a limit: strict comparisons
+            cur = rng.uniform(-1.5, 1.5, n)
+            out = ns["check_limits"](ref.tolist(), cur.tolist())
+            refs.append(np.pad(ref, (0, 14 - n), constant_values=np.nan))
+            curs.append(np.pad(cur, (0, 14 - n), constant_values=np.nan))
+            outs.append(np.pad(np.asarray(out, dtype=float), (0, 14 - n), constant_values=np.nan))
+    lims = np.full((len(seen), 14, 2), np.nan)
+    for k, lim in enumerate(seen):
+        lims[k, :len(lim)] = lim
+    np.savez(os.path.join(OUT, "jpctrl_golden.npz"), ref=np.stack(refs), cur_pos=np.stack(curs), limits=lims, ref_out=np.stack(outs))
+    print("jpctrl_golden.npz written: %d cases" % len(refs))
+
+
 if __name__ == "__main__":
     make_mixer_golden()
     make_nullspace_golden()
+    make_jpctrl_golden()

@@ -123,3 +123,26 @@ def test_rollout_with_joint_controller_converges_to_the_reference(env):
     assert np.abs(out["q"] - target).max() < 1e-4
     assert ((out["status"] & abi.ST_JOINT_AT_GOAL) != 0).all()
     eng.close()
+
+
+def test_kept_reference_equals_the_reference_clamp(env, golden_dir):
+    """io.q_ref_out (the reference the controller KEEPS, joint_p_controller:121) against the reference's own check_limits outputs
+    (tests/golden/jpctrl_golden.npz): limits that move with the position go in as this cycle's io.q_lo / io.q_hi."""
+    import os
+    abi = env["abi"]
+    g = np.load(os.path.join(golden_dir, "jpctrl_golden.npz"))
+    n_of = np.sum(~np.isnan(g["ref"]), axis=1)
+    for robot, n in (("powercube6", 6), ("lwr", 7), ("lwr_dual14", 14)):
+        sel = np.nonzero(n_of == n)[0]
+        chain = env["robots"].by_name(robot)
+        B = len(sel)
+        ref, lim, want = g["ref"][sel, :n], g["limits"][sel, :n], g["ref_out"][sel, :n]
+        w = env["synth"].make_workload(chain, B, 1, seed=3, io_dtype=np.float64)
+        params = abi.default_params(flags=abi.F_MIXER, mix_w=[0, 0, 1, 0, 0, 0], jp_kp=1.0)
+        eng = env["engine"].Engine(chain, B, io_dtype=np.float64, max_slots=2, device=0, params=params)
+        eng.set_fields(w["fields"], w["nfields"])
+        q = np.clip(g["cur_pos"][sel, :n], 0.9 * chain.q_lo, 0.9 * chain.q_hi)
+        got = eng.step_host(q, q_ref=ref, q_lo=lim[:, :, 0].copy(), q_hi=lim[:, :, 1].copy(), want=("qdot_out", "q_ref_out"))
+        assert np.array_equal(got["q_ref_out"], want), robot
+        assert np.abs(got["qdot_out"] - (want - q)).max() < 1e-12   # channel 2 alone: kp (clamp(ref) - q), kp = 1
+        eng.close()

@@ -208,3 +208,20 @@ def test_check_limits(golden_dir, oracle_c, n):
         assert t1 == t2
         tripped += t1
     assert 0 < tripped < len(g["n%d__lim_q" % n])
+
+
+def test_joint_controller_clamp_against_the_reference(golden_dir, oracle_c):
+    """scripts/joint_p_controller:79-89 `check_limits(ref, cur_pos)` as the reference itself computed it (round 3:
+    tests/golden/jpctrl_golden.npz, limits that move with the position): both restatements of the joint controller keep exactly
+    the reference's clamped reference -- kp = 1 and q = 0 make their command the clamped reference itself."""
+    import os
+    from oracle import vfik_numpy as vn
+    g = np.load(os.path.join(golden_dir, "jpctrl_golden.npz"))
+    for k in range(g["ref"].shape[0]):
+        n = int(np.sum(~np.isnan(g["ref"][k])))
+        ref, lim, want = g["ref"][k, :n], g["limits"][k, :n], g["ref_out"][k, :n]
+        cmd, _ = vn.joint_p_controller(ref.tolist(), np.zeros(n).tolist(), lim.tolist(), 1.0, 0.087)
+        assert np.array_equal(np.asarray(cmd), want)
+        out, _ = oracle_c.joint_p(ref[None, :], np.zeros((1, n)), lim[:, 0], lim[:, 1], 1.0, 0.087)
+        assert np.array_equal(out[0], want)
+    assert np.any(g["ref_out"] != g["ref"]) and np.any(g["ref_out"][~np.isnan(g["ref"])] == g["ref"][~np.isnan(g["ref"])])
