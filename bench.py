@@ -396,24 +396,26 @@ def worker(args):
     # direct launches or a captured graph of them: decided in the (untimed) warm-up, per --launch
     graph, launch_note = None, "direct: K vfik_step calls per region"
     if args.launch != "direct" and not args.sync_each:
+        g, why = None, ""
         try:
             g = capture(primary, K)
-            if args.launch == "graph":
-                graph = g
-            else:
-                d_s, _, _ = timed(primary, K, 5)
-                g_s, _, _ = timed(primary, K, 5, graph=g)
-                picks = reduce_max([pctl(d_s, 50), pctl(g_s, 50)])   # every rank takes the same decision: on the slowest rank's times
-                if picks[1] < 0.97 * picks[0]:
-                    graph = g
-                launch_note_trial = "warm-up trial, us per step: direct %.3f, graph %.3f" % (picks[0] * 1e6 / K, picks[1] * 1e6 / K)
-            if graph is not None:
-                launch_note = "hipGraph: one replay of K captured vfik_step launches per region"
-            if args.launch == "auto":
-                launch_note += " (auto; " + launch_note_trial + ")"
         except Exception as e:  # capture not possible on this stack: stay direct, say so
-            graph = None
-            launch_note = "direct (graph capture failed: %s)" % str(e).splitlines()[0][:120]
+            why = str(e).splitlines()[0][:120] if str(e) else type(e).__name__
+        # every rank takes the same path from here on (the trial regions carry barriers): graphs only if EVERY rank captured one
+        all_ok = reduce_max([0.0 if g is not None else 1.0])[0] == 0.0
+        if not all_ok:
+            launch_note = "direct (graph capture failed%s)" % (": " + why if why else " on another rank")
+        elif args.launch == "graph":
+            graph = g
+        else:
+            d_s, _, _ = timed(primary, K, 5)
+            g_s, _, _ = timed(primary, K, 5, graph=g)
+            picks = reduce_max([pctl(d_s, 50), pctl(g_s, 50)])   # one decision for all ranks: on the slowest rank's times
+            if picks[1] < 0.97 * picks[0]:
+                graph = g
+            launch_note += " (auto; warm-up trial, us per step: direct %.3f, graph %.3f)" % (picks[0] * 1e6 / K, picks[1] * 1e6 / K)
+        if graph is not None:
+            launch_note = launch_note.replace("direct: K vfik_step calls per region", "hipGraph: one replay of K captured vfik_step launches per region")
     wall_s, enqueue_s, ev_ms = timed(primary, K, R, graph=graph)
     own_wall_s = list(wall_s)
     wall_s = reduce_max(wall_s)        # per repetition: the slowest rank
