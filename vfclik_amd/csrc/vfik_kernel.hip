@@ -1120,6 +1120,9 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     // Chains of 8+ joints with the nullspace module: the projector of the joint-limit task,
     // z - J^T (J J^T)^-1 J z (see A10-A13 below), shares the IK's passes over the Jacobian.
     constexpr bool FUSEP = NULLSP && NJ >= 8;
+    // ... except with IK weights or a tool (general variant), or on the general field path: the undamped Gram matrix G = J J^T and J z are then accumulated in a
+    // pass of their own AFTER the IK's solve, when the weighted normal matrix is dead -- both matrices live at once spill
+    constexpr bool GLATE = FUSEP && (!PLAIN || (!FASTF && sizeof(T) == 4));  // (float64 I/O on the general path: 88 B of scratch without it, 176 with)
     double zp[FUSEP ? NJ : 1];
     if constexpr (FUSEP) {
         const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
@@ -1152,7 +1155,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
                 for (int r = 0; r < 6; ++r) {
 #pragma unroll
                     for (int c = 0; c <= r; ++c) Ae[ACCJ ? r : 0][c] = __builtin_fma(col[r], col[c], Ae[ACCJ ? r : 0][c]);
-                    if constexpr (FUSEP) wne[r] = __builtin_fma(col[r], zp[FUSEP ? i : 0], wne[r]);
+                    if constexpr (FUSEP && !GLATE) wne[r] = __builtin_fma(col[r], zp[FUSEP ? i : 0], wne[r]);
                 }
             }
             if (PLAIN) {
@@ -1219,11 +1222,11 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
 #pragma unroll
             for (int r = 0; r < 6; ++r) wyv[PLAIN ? 0 : r] = wts ? wts[(long)r * wpitch] : kc->wy[r];
         }
-        constexpr bool GFROMA = FUSEP && PLAIN;  // unit weights: G is A before the damping is added
+        constexpr bool GFROMA = FUSEP && PLAIN && !GLATE;  // unit weights: G is A before the damping is added
         if constexpr (ACCJ) {  // accumulated with the Jacobian columns above
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                wn[r] = wne[r];
+                if constexpr (!GLATE) wn[r] = wne[r];
 #pragma unroll
                 for (int c = 0; c <= r; ++c) A[r][c] = Ae[ACCJ ? r : 0][c];
                 if constexpr (!GFROMA) A[r][r] += kc->lambda2;
@@ -1233,7 +1236,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
             for (int r = 0; r < 6; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && PLAIN) ? kc->lambda2 : 0.0;
-            if constexpr (FUSEP) {
+            if constexpr (FUSEP && !GLATE) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     wn[r] = 0.0;
@@ -1253,7 +1256,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
                 for (int r = 0; r < 6; ++r) {
 #pragma unroll
                     for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(PLAIN ? Jm[i][r] : t[r], Jm[i][c], A[r][c]);
-                    if constexpr (FUSEP) {
+                    if constexpr (FUSEP && !GLATE) {
                         wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
                         if constexpr (!PLAIN) {
 #pragma unroll
@@ -1534,6 +1537,23 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
 #pragma unroll
             for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k];
             y[i] = t;
+        }
+        if constexpr (GLATE) {
+            asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]));  // (behind the solve)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                wn[r] = 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    wn[r] = __builtin_fma(Jm[i][r], zp[FUSEP ? i : 0], wn[r]);
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = __builtin_fma(Jm[i][r], Jm[i][c], G[FUSEP ? r : 0][c]);
+                }
         }
         if constexpr (FUSEP) {
             // LDL^T of the undamped Gram matrix; a vanishing pivot (singular pose) drops that direction

@@ -323,6 +323,8 @@ class ControlCycleBatch:
         if ref is not None:  # the controller keeps the CLAMPED reference (joint_p_controller:121)
             upd = got_q & self.has_ref
             self.q_ref[upd] = out["q_ref_out"][upd]
+        else:
+            out["q_ref_out"] = None  # (the key set of `last` does not vary between cycles)
         out["track_error"] = out["track_error"].astype(np.float64)
         dists = out["object_dist"] = out.pop("obj_dist").astype(np.float64) if n_obj else None
         self.last = out
