@@ -142,15 +142,27 @@ def test_a_stuck_rank_times_out_and_everything_is_terminated(tmp_path):
 def test_rank_cpu_shares_are_disjoint_and_cover_every_rank():
     from vfclik_amd import launcher
     cpus = list(range(16, 48))
-    shares = [launcher.rank_cpus(r, 8, cpus) for r in range(8)]
+    solo = [[c] for c in cpus]                      # no SMT: every CPU its own core
+    shares = [launcher.rank_cpus(r, 8, cpus, groups=solo) for r in range(8)]
     assert all(len(s) == 4 for s in shares)
     flat = [c for s in shares for c in s]
     assert len(set(flat)) == len(flat) and set(flat) <= set(cpus)
-    assert launcher.rank_cpus(0, 2, list(range(64))) == list(range(8))          # capped at 8 per rank
-    assert launcher.rank_cpus(1, 2, list(range(64)), max_per_rank=0) == list(range(32, 64))
-    assert launcher.rank_cpus(5, 8, [3, 4]) == [4]                              # fewer CPUs than ranks: shared
+    assert launcher.rank_cpus(0, 2, list(range(64)), groups=[[c] for c in range(64)]) == list(range(8))          # capped at 8 per rank
+    assert launcher.rank_cpus(1, 2, list(range(64)), max_per_rank=0, groups=[[c] for c in range(64)]) == list(range(32, 64))
+    assert launcher.rank_cpus(5, 8, [3, 4], groups=[[3], [4]]) == [4]                              # fewer cores than ranks: shared
     with pytest.raises(ValueError):
         launcher.rank_cpus(2, 2, cpus)
+    # SMT: CPUs c and c + 128 are the two threads of core c (a 128-core, 256-thread host): eight ranks get eight DIFFERENT sets
+    # of physical cores -- rank 4 must not land on the siblings of rank 0's cores
+    smt = [[c, c + 128] for c in range(128)]
+    shares = [launcher.rank_cpus(r, 8, list(range(256)), groups=smt) for r in range(8)]
+    cores = [{c % 128 for c in s} for s in shares]
+    assert all(len(s) == 8 and len(k) == 4 for s, k in zip(shares, cores))       # 4 cores x 2 threads
+    assert all(cores[a].isdisjoint(cores[b]) for a in range(8) for b in range(a + 1, 8))
+    assert shares[0] == [0, 1, 2, 3, 128, 129, 130, 131] and shares[4][0] == 64
+    # the topology of THIS machine, whatever it is: shares of different ranks never share a core
+    groups = launcher._sibling_groups(set(launcher.allowed_cpus()))
+    assert sorted(c for g in groups for c in g) == launcher.allowed_cpus()
 
 
 def test_pin_rank_narrows_the_affinity_of_a_fresh_process(tmp_path):

@@ -40,18 +40,48 @@ def allowed_cpus():
         return list(range(os.cpu_count() or 1))
 
 
-def rank_cpus(local_rank, local_world, cpus=None, max_per_rank=8):
-    """The slice of `cpus` (default: this process's cpuset) that rank `local_rank` of `local_world` pins itself to:
-    contiguous, disjoint, equal shares, at most `max_per_rank` CPUs each (the enqueue loop is one thread; HIP's helper
-    threads want a few more).  With fewer CPUs than ranks, several ranks share one CPU (round-robin)."""
+def _sibling_groups(cpus):
+    """The allowed logical CPUs grouped by physical core (hardware threads of one core together), cores ordered by their lowest
+    CPU number; every CPU a group of its own when the topology is not readable."""
+    groups, seen = [], set()
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        sib = {c}
+        try:
+            txt = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+            for part in txt.split(","):
+                lo, _, hi = part.partition("-")
+                sib.update(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            pass
+        sib = sorted(x for x in sib if x in cpus and x not in seen)
+        seen.update(sib)
+        groups.append(sib)
+    return groups
+
+
+def rank_cpus(local_rank, local_world, cpus=None, max_per_rank=8, groups=None):
+    """The CPUs rank `local_rank` of `local_world` pins itself to: a contiguous, disjoint, equal share of the PHYSICAL cores of the
+    process's cpuset (`cpus`, default: its affinity mask), with all hardware threads of those cores -- two ranks never share a core --
+    at most `max_per_rank` logical CPUs each (the enqueue loop is one thread; HIP's helper threads want a few more).  With fewer cores
+    than ranks, several ranks share one core (round-robin).  `groups` (lists of sibling CPUs) overrides the topology read from sysfs."""
     cpus = allowed_cpus() if cpus is None else sorted(cpus)
     if not cpus or local_world < 1 or not (0 <= local_rank < local_world):
         raise ValueError("bad rank %d / world %d / cpus %r" % (local_rank, local_world, cpus))
-    per = len(cpus) // local_world
+    cores = [list(g) for g in groups] if groups is not None else _sibling_groups(set(cpus))
+    per = len(cores) // local_world
     if per < 1:
-        return [cpus[local_rank % len(cpus)]]
-    mine = cpus[local_rank * per:(local_rank + 1) * per]
-    return mine[:max_per_rank] if max_per_rank else mine
+        return list(cores[local_rank % len(cores)])
+    mine = [c for g in cores[local_rank * per:(local_rank + 1) * per] for c in g]
+    if max_per_rank and len(mine) > max_per_rank:   # whole cores first: keep the leading cores' threads
+        out = []
+        for g in cores[local_rank * per:(local_rank + 1) * per]:
+            if len(out) + len(g) > max_per_rank:
+                break
+            out.extend(g)
+        mine = out or mine[:max_per_rank]
+    return sorted(mine)
 
 
 def pin_rank(local_rank, local_world, log=None):
