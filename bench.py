@@ -246,14 +246,15 @@ def worker(args):
         cpu["os_cpu_count"] = os.cpu_count()
         cpu["best_cpu"] = c_oracle_rate(chain, params, w, cores)
 
-    # each rank on its own cores, before the first GPU call (the HIP runtime's threads inherit the mask); printed on stderr
+    import torch
+    import torch.distributed as dist
+
+    # each rank on its own cores (near its GPU's NUMA node where sysfs tells), before the first GPU call: the HIP runtime's threads
+    # inherit the mask; printed on stderr.  (device_count() initialises nothing.)
     binding = None
     if world > 1:
         from vfclik_amd import launcher
-        binding = launcher.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-
-    import torch
-    import torch.distributed as dist
+        binding = launcher.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), visible_gpus=torch.cuda.device_count())
 
     from vfclik_amd import engine, sharding
 

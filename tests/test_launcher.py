@@ -183,3 +183,22 @@ def test_pin_rank_narrows_the_affinity_of_a_fresh_process(tmp_path):
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom vfclik_amd import launcher\nassert launcher.pin_rank(0, 2) is None" % ROOT],
                        capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 0, r.stderr
+
+
+def test_rank_cpus_near_the_gpu_numa_node():
+    """Two sockets of 64 cores x 2 threads, GPUs 0-3 on node 0 and 4-7 on node 1: every rank gets cores of ITS GPU's node, the four ranks
+    of a node split that node's cores, nobody shares a core; unknown or short node lists fall back to the plain split."""
+    from vfclik_amd import launcher
+    cpus = list(range(256))
+    smt = [[c, c + 128] for c in range(128)]
+    node0 = set(range(0, 64)) | set(range(128, 192))
+    node1 = set(range(64, 128)) | set(range(192, 256))
+    lists = [node0] * 4 + [node1] * 4
+    shares = [launcher.rank_cpus_near_gpu(r, 8, cpus, lists, groups=smt) for r in range(8)]
+    for r, s in enumerate(shares):
+        assert set(s) <= (node0 if r < 4 else node1) and len(s) == 8
+    cores = [{c % 128 for c in s} for s in shares]
+    assert all(cores[a].isdisjoint(cores[b]) for a in range(8) for b in range(a + 1, 8))
+    assert launcher.rank_cpus_near_gpu(1, 2, cpus, None if launcher.gpu_local_cpus() is None else [node0], groups=smt) == launcher.rank_cpus(1, 2, cpus, groups=smt)
+    assert launcher.rank_cpus_near_gpu(0, 2, cpus, [set(), set()], groups=smt) == launcher.rank_cpus(0, 2, cpus, groups=smt)
+    assert launcher._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}

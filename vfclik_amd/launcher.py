@@ -84,19 +84,68 @@ def rank_cpus(local_rank, local_world, cpus=None, max_per_rank=8, groups=None):
     return sorted(mine)
 
 
-def pin_rank(local_rank, local_world, log=None):
+def _parse_cpulist(txt):
+    out = set()
+    for part in txt.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus():
+    """Per GPU (amdgpu PCI devices in bus order, which is how the HIP runtime numbers them unless a *_VISIBLE_DEVICES variable
+    re-maps them), the CPUs of its NUMA node (`local_cpulist`).  None when that cannot be read or devices are re-mapped."""
+    import glob
+    if any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return None
+    try:
+        devs = sorted(d for d in glob.glob("/sys/bus/pci/drivers/amdgpu/*:*:*.*") if os.path.exists(os.path.join(d, "local_cpulist")))
+        lists = [_parse_cpulist(open(os.path.join(d, "local_cpulist")).read()) for d in devs]
+    except (OSError, ValueError):
+        return None
+    return lists if lists and all(lists) else None
+
+
+def rank_cpus_near_gpu(local_rank, local_world, cpus=None, gpu_lists=None, max_per_rank=8, groups=None):
+    """rank_cpus, but inside the NUMA node of the rank's GPU: the ranks whose GPUs share a node split THAT node's cores among
+    themselves.  Falls back to rank_cpus over the whole cpuset when the node lists are unknown, do not cover every rank, or leave a
+    rank without a CPU of the process's cpuset."""
+    cpus = allowed_cpus() if cpus is None else sorted(cpus)
+    gpu_lists = gpu_local_cpus() if gpu_lists is None else gpu_lists
+    if not gpu_lists or len(gpu_lists) < local_world:
+        return rank_cpus(local_rank, local_world, cpus, max_per_rank, groups)
+    mine = frozenset(gpu_lists[local_rank]) & set(cpus)
+    peers = [r for r in range(local_world) if frozenset(gpu_lists[r]) & set(cpus) == mine]
+    if not mine:
+        return rank_cpus(local_rank, local_world, cpus, max_per_rank, groups)
+    sub_groups = None
+    if groups is not None:
+        sub_groups = [[c for c in g if c in mine] for g in groups]
+        sub_groups = [g for g in sub_groups if g]
+    return rank_cpus(peers.index(local_rank), len(peers), sorted(mine), max_per_rank, sub_groups)
+
+
+def pin_rank(local_rank, local_world, log=None, visible_gpus=None):
     """Pin the calling process (a rank, BEFORE its first GPU call: the HIP runtime's threads inherit the mask) to its own
-    cores, so that eight 4-us enqueue loops on one host do not migrate over each other.  Prints the binding.
-    VFIK_NO_PIN=1 leaves the process where the launcher put it.  Returns the CPU list, or None when nothing was done."""
+    cores -- near its GPU's NUMA node where sysfs tells -- so that eight 4-us enqueue loops on one host do not migrate over each
+    other.  Prints the binding.  VFIK_NO_PIN=1 leaves the process where the launcher put it.  Returns the CPU list, or None when
+    nothing was done."""
     if os.environ.get("VFIK_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
         return None
-    mine = rank_cpus(local_rank, local_world)
+    # the GPU's NUMA node is used only when sysfs and the runtime agree on how many GPUs there are (a container that sees one GPU
+    # of eight cannot tell which one from its index): visible_gpus = the runtime's device count, from a call that initialises nothing
+    lists = gpu_local_cpus()
+    if lists is not None and visible_gpus is not None and len(lists) != int(visible_gpus):
+        lists = None
+    mine = rank_cpus_near_gpu(local_rank, local_world, gpu_lists=lists) if lists else rank_cpus(local_rank, local_world)
     try:
         os.sched_setaffinity(0, mine)
     except OSError as e:  # a cpuset we may not narrow: keep running unpinned
         print("rank %d: sched_setaffinity(%s) failed: %s" % (local_rank, mine, e), file=sys.stderr, flush=True)
         return None
-    print("rank %d of %d on this host: pinned to CPUs %s" % (local_rank, local_world, ",".join(map(str, mine))),
+    print("rank %d of %d on this host: pinned to CPUs %s%s" % (local_rank, local_world, ",".join(map(str, mine)),
+                                                                " (NUMA node of GPU %d)" % local_rank if lists else ""),
           file=log or sys.stderr, flush=True)
     return mine
 
