@@ -46,7 +46,14 @@ struct KConst {
     // (crev, cprs, sprs, qd) = (1, 0, 0, 0), prismatic ones (0, cos off, sin off, 1) -- arithmetic blends
     struct DH { double off, crev, cprs, sprs, qd, d, a, ca, sa, pad; } dh[NJ];
     double tail_c, tail_s, tail_e, tail_pad;  // trailing z-screw of the last fixed transform
-    // ---- everything else: read through the scalar cache
+    // ---- everything else: read through the scalar cache.  Ordered by use on the lean paths: the first members share the 1-KiB
+    // rows that every wave copies to LDS for the kinematics block, so the L2 has them by the time the scalar loads ask -- with
+    // one handle after another (inputs from HBM) the first use of lambda2 / rot_slow cost the wave an HBM round trip (round 3).
+    double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
+    double cos_slow;  // cos(rot_slow): rotation angles with a smaller cosine need no atan2 (scalar = 1)
+    double jp_kp, jp_delta;  // joint P controller (joint_p_controller:55-57)
+    double jl_gain;          // gain of the joint-limit task (jl_k is jl_gain / half^2 of the STATIC limits; per-cycle limits use this)
+    double mix_w[VFIK_MIX_CHANNELS];
     double q_lo[NJ];
     double q_hi[NJ];
     double q_mid[NJ];     // (lo + hi) / 2
@@ -54,12 +61,7 @@ struct KConst {
     double jl_k[NJ];      // jl_gain / half^2
     double wq[NJ];
     double wy[6];
-    double mix_w[VFIK_MIX_CHANNELS];
     double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
-    double speed, lambda2, rot_slow, null_gain, lookahead, max_vel;
-    double cos_slow;  // cos(rot_slow): rotation angles with a smaller cosine need no atan2 (scalar = 1)
-    double jp_kp, jp_delta;  // joint P controller (joint_p_controller:55-57)
-    double jl_gain;          // gain of the joint-limit task (jl_k is jl_gain / half^2 of the STATIC limits; per-cycle limits use this)
     unsigned prismatic_mask;
     unsigned pad0;
     static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
