@@ -64,7 +64,7 @@ struct KConst {
     double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
     unsigned prismatic_mask;
     unsigned pad0;
-    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4) * 8;
+    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4 + 10 + VFIK_MIX_CHANNELS) * 8;  // through mix_w: the block every wave copies to LDS
     static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
 // The device image of the constants is KConst<NJ> padded to a multiple of 1 KiB, then the 1-KiB sin / cos table

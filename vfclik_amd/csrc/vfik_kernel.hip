@@ -631,7 +631,7 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int q16(int nj) { return qbytes(nj) / 16; }
     __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
-    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4) * 8 + 1023) / 1024; }
+    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4 + 10 + VFIK_MIX_CHANNELS) * 8 + 1023) / 1024; }  // = KConst<nj>::KIN_ROWS
     __host__ __device__ static constexpr int kin_off(int nj) { return Q_OFF + qregion(nj); }
     __host__ __device__ static constexpr int tab_off(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }  // sin / cos table, 1 KiB
     __host__ __device__ static constexpr int lean_bytes(int nj) { return tab_off(nj) + 1024; }
@@ -704,6 +704,11 @@ template <typename T> struct SlotLds {
 #define VFIK_NT_MIN_NJ 0
 #endif
 
+
+// A scalar of the lean paths (lambda2, rot_slow, mix_w ...): they sit behind the kinematics block in KConst and travel to LDS with it.
+// Long chains read them from that LDS copy (C5 -1.5 % in both cache states: no scalar-load round trip in front of the IK and the
+// attractor); chains of up to 7 joints keep the scalar loads (from the LDS copy: C3 +0.2-0.3 %, C3N +0.6-1.2 %).
+#define HOTK(member) (NJ >= 10 ? klc->member : kc->member)
 
 #define VFIK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -1229,13 +1234,13 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
                 if constexpr (!GLATE) wn[r] = wne[r];
 #pragma unroll
                 for (int c = 0; c <= r; ++c) A[r][c] = Ae[ACCJ ? r : 0][c];
-                if constexpr (!GFROMA) A[r][r] += kc->lambda2;
+                if constexpr (!GFROMA) A[r][r] += HOTK(lambda2);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && PLAIN) ? kc->lambda2 : 0.0;
+                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && PLAIN) ? HOTK(lambda2) : 0.0;
             if constexpr (FUSEP && !GLATE) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
@@ -1269,7 +1274,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(wyv[PLAIN ? 0 : r] * wyv[PLAIN ? 0 : c], A[r][c], r == c ? kc->lambda2 : 0.0);
+                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(wyv[PLAIN ? 0 : r] * wyv[PLAIN ? 0 : c], A[r][c], r == c ? HOTK(lambda2) : 0.0);
             }
         }
         if constexpr (GFROMA) {
@@ -1277,7 +1282,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
             for (int r = 0; r < 6; ++r) {
 #pragma unroll
                 for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = A[r][c];
-                A[r][r] += kc->lambda2;
+                A[r][r] += HOTK(lambda2);
             }
         }
         // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
@@ -1324,7 +1329,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
                 Gp[r] = gq[4 * r + 3];
             }
             // a.goal_dist requested: the angle is needed whatever its size (cos_slow = -2 forces atan2)
-            attractor(Rt, pt, GR, Gp, gq[13], gq[14], kc->rot_slow, a.goal_dist ? -2.0 : kc->cos_slow, gq[12] != 0.0, tot, sc, gdist);
+            attractor(Rt, pt, GR, Gp, gq[13], gq[14], HOTK(rot_slow), a.goal_dist ? -2.0 : HOTK(cos_slow), gq[12] != 0.0, tot, sc, gdist);
         }
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
@@ -1418,7 +1423,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
             // slot cost a round trip of its own (C3 with one odd arm: 10.9 us per launch) -- the rest, and
             // entries that would straddle the staged window, from the quad planes.
             const SlotLds<T> rl{dreg, lanec, NJ};
-            const double rs = kc->rot_slow, csl = kc->cos_slow;
+            const double rs = HOTK(rot_slow), csl = HOTK(cos_slow);
             for (int c0 = 0; c0 < a.slots_used; c0 += PRE) {  // chunks of PRE slots through the staged rows
                 if (c0 > 0) {  // (no overlap with the previous chunk's arithmetic here: its entries read the rows lazily)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1660,7 +1665,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         // scalar load and wait (~200 cycles a joint).
         double lo[NJ], hi[NJ];
         limits_of(lo, hi);
-        const double look = kc->lookahead, ngain = kc->null_gain;
+        const double look = HOTK(lookahead), ngain = HOTK(null_gain);
         int bad = 0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
@@ -1683,8 +1688,8 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
             read_quad<T>(region, Stage<T>::mixw_off(NJ) + Stage<T>::QSTEP, lanec, mw + 4);
         } else {
 #pragma unroll
-            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = kc->mix_w[k];
-            mw[6] = kc->max_vel;
+            for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) mw[k] = HOTK(mix_w[k]);
+            mw[6] = HOTK(max_vel);
         }
     }
     if (a.flags & VFIK_F_MIXER) {
