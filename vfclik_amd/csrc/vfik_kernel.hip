@@ -1012,9 +1012,14 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     const KConst<NJ>* klc = kl;
     int lanec = lane;
     KcPtr kc = kc_launch;
-    if (ROLL && NJ >= 10) {  // long chains have no registers to spare for cycle-invariant copies of the inputs
-        asm volatile("" : "+v"(klc));
-        asm volatile("" : "+v"(lanec));
+    if (ROLL && (NJ >= 10 || !PLAIN)) {  // long chains / the general variant have no registers to spare for cycle-invariant copies of the inputs
+        // (an opaque ZERO added to the LDS address and the lane: the reads stay LDS reads -- an opaque pointer would turn them
+        // into flat loads -- but the compiler can no longer prove them cycle-invariant)
+        int zero_v = 0, zero_s = 0;
+        asm volatile("" : "+v"(zero_v));
+        asm volatile("" : "+s"(zero_s));
+        klc = reinterpret_cast<const KConst<NJ>*>(reinterpret_cast<const char*>(kl) + zero_s);
+        lanec = lane + zero_v;
         asm volatile("" : "+s"(kc));  // nor SGPRs for ~70 hoisted scalar constants (they would spill through VGPR lanes)
     }
     // Joint limits of this cycle: the arm's own (io.q_lo / q_hi; nullspace:167 and joint_p_controller:80 re-read
