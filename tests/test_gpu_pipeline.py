@@ -131,3 +131,34 @@ def test_sharded_engine_on_the_gpu_splits_a_batch_over_handles():
     for k in ("qdot_out", "pose", "status"):
         assert np.array_equal(out[k], ref[k]), k   # per-arm decisions: the split changes nothing, bit for bit
     sh.close()
+
+
+def test_output_rows_through_unaligned_pointers_and_partial_waves():
+    """The LDS-tiled coalesced stores of the published rows (put_rows) need 16-byte aligned output pointers and full waves;
+    anything else takes the lane-by-lane stores.  Same results either way: outputs handed in at a 4-byte offset, and a batch
+    whose last wave is partial, against the aligned run of the same batch."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from vfclik_amd import _abi, engine, robots, synth
+    chain = robots.lwr()
+    B = 64 * 70 + 19                       # beyond the small-batch kernel's 4 096 arms; last wave partial
+    w = synth.make_workload(chain, B, 5, seed=31, io_dtype=np.float32)
+    params = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+    shapes = {"qdot_out": 7, "qdot_vf": 7, "qdot_null": 7, "pose": 16, "pose_nt": 16, "qdist": 7, "v6": 6, "goal_dist": 2}
+    res = []
+    for off in (0, 1):
+        eng = engine.Engine(chain, B, io_dtype=np.float32, max_slots=6, params=params)
+        eng.set_fields(w["fields"], w["nfields"])
+        eng.use_stream(torch.cuda.current_stream().cuda_stream)
+        q = torch.from_numpy(w["q"].astype(np.float32)).cuda()
+        flat = {k: torch.zeros(B * c + off, dtype=torch.float32, device="cuda") for k, c in shapes.items()}
+        outs = {k: flat[k][off:] for k in shapes}                      # off = 1: every pointer 4 bytes past a 16-byte boundary
+        assert all((outs[k].data_ptr() % 16 == 0) == (off == 0) for k in shapes)
+        eng.step(eng.make_io(q, **outs))
+        torch.cuda.synchronize()
+        res.append({k: outs[k].cpu().numpy().reshape(B, shapes[k]).copy() for k in shapes})
+        eng.close()
+    for k in shapes:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert np.abs(res[0]["pose"][:, 15] - 1.0).max() == 0.0 and np.abs(res[0]["qdot_out"]).max() > 1e-3
