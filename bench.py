@@ -52,6 +52,8 @@ WORKLOADS = {
     # + (16 + 16 + 3 n + 1) scalars): 384 + 54 x 4 = 600 B, 696 + 75 x 4 = 996 B
     "C3F": ("lwr", 65536, 8, "float32", 1 | 4, 600, FULL_OUTS),
     "C5F": ("lwr_dual14", 65536, 16, "float32", 1 | 2 | 4, 996, FULL_OUTS),
+    # C2's batch with vfclik's default process set publishing every per-cycle row: the eight-lanes-per-arm kernel <double, 7, NS>
+    "C2F": ("lwr", 4096, 4, "float64", 1 | 4, 512 + 54 * 8, FULL_OUTS),
 }
 
 MIB = 1 << 20
@@ -160,7 +162,7 @@ def kernel_name(io_name, n, flags, batch, sub8, full=False):
     workloads are revolute chains with identity tool, unit weights, integer-order repellers and qdot_out only."""
     t = "float" if io_name == "float32" else "double"
     if sub8:
-        return "vfik::cycle_sub8_kernel<%s,%d>" % (t, n)
+        return "vfik::cycle_sub8_kernel<%s,%d,%s>" % (t, n, "true" if flags & 1 else "false")
     if full:  # the per-cycle rows asked for, no per-arm option: the publishing lean variant (LEAN 3)
         cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
         return "vfik::cycle_kernel<%s,%d,%s,true,false,true,3,%d>" % (t, n, "true" if flags & 1 else "false", cf)

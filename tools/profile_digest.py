@@ -12,8 +12,8 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALG = {"C2": 512 * 4096, "C3": 384 * 65536, "C3N": 384 * 65536, "C5": 696 * 65536, "C3F": 600 * 65536, "C5F": 996 * 65536}
-WAVES = {"C2": 4096 // 8, "C3": 1024, "C3N": 1024, "C5": 1024, "C3F": 1024, "C5F": 1024}
+ALG = {"C2": 512 * 4096, "C3": 384 * 65536, "C3N": 384 * 65536, "C5": 696 * 65536, "C3F": 600 * 65536, "C5F": 996 * 65536, "C2F": 944 * 4096}
+WAVES = {"C2": 4096 // 8, "C3": 1024, "C3N": 1024, "C5": 1024, "C3F": 1024, "C5F": 1024, "C2F": 4096 // 8}
 
 
 def one(pattern):
@@ -38,7 +38,7 @@ def main():
     d, rnd = sys.argv[1], int(sys.argv[2])
     print("| workload | state | kernel | dispatches | rocprofv3 mean ns | median | min | frac from the CSV mean | the traced process's own HIP events, us | plain run (no tracer): us per launch, frac |")
     print("|---|---|---|---|---|---|---|---|---|---|")
-    for w in ("C2", "C3", "C3N", "C5", "C3F", "C5F"):
+    for w in ("C2", "C2F", "C3", "C3N", "C5", "C3F", "C5F"):
         plain = line_of(os.path.join(d, "bench_%s.json" % w))
         for state, tdir, under in (("warm", "trace_", "bench_under_rocprof_%s.json"), ("cold", "cold_trace_", "bench_cold_under_rocprof_%s.json")):
             st = one(os.path.join(d, tdir + w, "*", "*kernel_stats.csv"))
@@ -91,7 +91,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     print()
-    for w in ("C2", "C3", "C3N", "C5", "C3F", "C5F"):
+    for w in ("C2", "C2F", "C3", "C3N", "C5", "C3F", "C5F"):
         f = one(os.path.join(d, "pmc_sq_" + w, "*", "*counter_collection.csv"))
         if not f:
             continue
