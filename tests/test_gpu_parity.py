@@ -683,3 +683,104 @@ def test_slot_counts_around_the_chunk_boundaries(env, robot, nobs):
     params = env.abi.default_params(flags=flags)
     got, ref = _run_both(env, chain, params, w, np.float32, want=("qdot_out", "status"), max_slots=nobs)
     _compare(got, ref, TOL32, ("qdot_out", "status"))
+
+
+def _goal_and_normal_scene(env, chain, B, dt, n_obstacles, rng, funnel_share=1.0):
+    """What object_feeder sends for a goal with an approach vector (object_feeder:248-303): attractor (id 1), funnel attractor
+    (id 2, force 30, orders 10 / 2), near-goal repeller (id 3, 5 cm up the approach axis), then point obstacles (ids 4 ...)."""
+    f = env.abi
+    w = env.synth.make_workload(chain, B, n_obstacles, seed=int(rng.integers(1 << 30)), io_dtype=dt, max_fields=3 + n_obstacles)
+    F = w["fields"]
+    M = F.shape[1]
+    # shift the obstacles behind the funnel and the near-goal repeller
+    F[:, 3:3 + n_obstacles] = F[:, 1:1 + n_obstacles].copy()
+    goal_p = F["p"][:, 0, [3, 7, 11]]
+    axis = F["p"][:, 0, [2, 6, 10]]          # approach along the goal frame's z axis
+    F["id"][:, 1], F["type"][:, 1], F["force"][:, 1] = 2, f.FIELD_FUNNEL, 30.0
+    F["p"][:, 1] = 0.0
+    F["p"][:, 1, 0:3] = goal_p
+    F["p"][:, 1, 3:6] = axis
+    F["p"][:, 1, 6:10] = [0.15, 10.0, 0.15, 2.0]
+    F["id"][:, 2], F["type"][:, 2], F["force"][:, 2] = 3, f.FIELD_REPELLER, -10.0
+    F["p"][:, 2] = 0.0
+    F["p"][:, 2, 0:3] = goal_p + 0.05 * axis
+    F["p"][:, 2, 3:6] = [0.15 + 0.05, 0.001, 5.0]
+    F["p"] = F["p"].astype(dt).astype(np.float64)
+    w["nfields"][:] = M
+    no_funnel = rng.uniform(size=B) >= funnel_share        # some arms: goal + obstacles only (type 0 leaves the entry empty)
+    F["type"][no_funnel, 1] = f.FIELD_NULL
+    return w
+
+
+@pytest.mark.parametrize("robot,B,dt,tol,flags,nobs", [
+    ("lwr", 65536, np.float32, TOL32, 0, 5),        # the C3 batch in the goalAndNormal scene, lean
+    ("lwr", 5000, np.float64, TOL64, 5, 5),         # default process set, every output (the publishing lean variant)
+    ("lwr", 333, np.float64, TOL64, 7, 11),         # more repellers than one staged chunk, joint-limit task
+    ("powercube6", 700, np.float32, TOL32, 5, 2),
+    ("lwr_dual14", 4200, np.float32, TOL32, 7, 6),
+    ("lwr", 64, np.float64, TOL64, 0, 0),           # funnel and near-goal repeller alone
+])
+def test_goal_and_normal_scene_on_the_straight_line_path(env, robot, B, dt, tol, flags, nobs):
+    """handlers.go_cart with a normal -> object_feeder's goalAndNormal: the funnel travels in its own block and the scene stays on the
+    straight-line field path (vfik_field_path == 2); every output against the oracle, arms with and without a funnel in one batch."""
+    chain = env.robots.by_name(robot)
+    rng = np.random.default_rng(B + nobs)
+    w = _goal_and_normal_scene(env, chain, B, dt, nobs, rng, funnel_share=0.8)
+    params = env.abi.default_params(flags=flags)
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=4 + nobs, params=params)
+    eng.set_small_batch_kernel(0)
+    eng.set_fields(w["fields"], w["nfields"])
+    assert eng.field_path == 2
+    want = ("qdot_out", "status") if flags == 0 and B > 10000 else ALL
+    # (/control only where the nullspace is one-dimensional: with nullity >= 2 it is the declared gap, vfik_io.null_control)
+    ctrl = rng.uniform(-1, 1, (B, 4)) if (flags & 1 and chain.n <= 7) else None
+    got = eng.step_host(w["q"], null_control=ctrl, want=want)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], null_control=ctrl)
+    _compare(got, ref, tol, want)
+    # the same scene with ONE arm outside the pattern (a fractional decay order) takes the general path: same results
+    F2 = w["fields"].copy()
+    F2["p"][B // 2, 2, 5] = 3.5
+    eng.set_fields(F2, w["nfields"])
+    assert eng.field_path == 0
+    got2 = eng.step_host(w["q"], null_control=ctrl, want=want)
+    keep = np.arange(B) != B // 2
+    for k in want:
+        if k != "status":
+            assert np.abs(got2[k][keep].astype(np.float64) - got[k][keep].astype(np.float64)).max() < tol
+    # ... and back, by a partial update of that arm alone
+    eng.set_fields(w["fields"][B // 2:B // 2 + 1], w["nfields"][B // 2:B // 2 + 1], first_arm=B // 2)
+    assert eng.field_path == 2
+    eng.close()
+
+
+def test_field_path_classification(env):
+    chain = env.robots.lwr()
+    f = env.abi
+    B = 8
+    w = env.synth.make_workload(chain, B, 3, seed=2, io_dtype=np.float64, max_fields=6)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float64, max_slots=12)
+    eng.set_fields(w["fields"], w["nfields"])
+    assert eng.field_path == 1
+    F = w["fields"].copy()
+    n = w["nfields"].copy()
+    F[0, 4]["id"], F[0, 4]["type"], F[0, 4]["force"] = 2, f.FIELD_FUNNEL, 30.0
+    F[0, 4]["p"][:10] = [0.3, 0.2, 0.5, 0, 0, 1, 0.15, 10.0, 0.15, 2.0]
+    n[0] = 5
+    eng.set_fields(F, n)
+    assert eng.field_path == 2                     # one funnel with integer orders: the funnel block
+    F[0, 5] = F[0, 4]
+    F[0, 5]["id"] = 50
+    n[0] = 6
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # a second funnel: general
+    n[0] = 5
+    F[0, 4]["p"][7] = 2.5
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # fractional angle order: general
+    F[0, 4]["p"][7] = 10.0
+    F[1, 4]["id"], F[1, 4]["type"], F[1, 4]["force"] = 9, f.FIELD_HEMISPHERE, -50.0
+    F[1, 4]["p"][:8] = [0.2, -0.1, -0.5, 0.05, -0.02, 1.0, 0.05, 5.0]
+    n[1] = 5
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # a hemisphere anywhere: general
+    eng.close()

@@ -73,6 +73,7 @@ struct vfik_handle {
     // device state
     void* d_arena = nullptr;   // [goal | kconst | lastvec | slots_fast | slots]: d_goal, d_kconst, d_lastvec, d_slots_fast, d_slots point into it
     void* d_goal = nullptr;    // 4 quad planes
+    void* d_funnel = nullptr;  // 3 quad planes: the arm's funnel attractor on the straight-line path (vfik_kernel.h)
     void* d_slots = nullptr;   // 2*S quad planes
     void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
     void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
@@ -97,6 +98,10 @@ struct vfik_handle {
     // host bookkeeping
     std::vector<double> bridge_host;  // [B][8] mirror of d_mixw_arm: mixer weights 0..5, max_vel 6
     std::vector<int> slots_per_arm;
+    std::vector<int> fast_slots_per_arm;  // slots of the compact repeller image per arm (the funnel is not one)
+    std::vector<char> arm_has_funnel;
+    int slots_used_fast = 0;
+    int any_funnel = 0;
     std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
     int fast_order = 0;
@@ -157,7 +162,9 @@ void put(std::vector<char>& buf, size_t idx, double v) {
 // (P * n_arms + j) * 4 + c): goal = 4 planes, slots = 2*S planes (vfik_kernel.h).
 template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
-                 std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used) {
+                 std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used,
+                 std::vector<char>& funnel, std::vector<int>& used_fast, std::vector<char>& has_funnel) {
+    funnel.assign((size_t)3 * n_arms * 4 * sizeof(T), 0);
     goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
     slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
     // compact image: a decay repeller needs 6 of its slot's 8 scalars (x y z radius safe | force; the decay order is
@@ -170,8 +177,8 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
         order.resize(counts[j]);
         for (int k = 0; k < counts[j]; ++k) order[k] = k;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f[a].id < f[b].id; });
-        bool have_goal = false;
-        int m = 0;
+        bool have_goal = false, have_funnel = false;
+        int m = 0, mr = 0;  // general slots used; compact-image slots used (repellers only, packed densely)
         auto gq = [&](int e) { return ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3); };
         for (int k : order) {
             const vfik_field& fd = f[k];
@@ -189,8 +196,15 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
             for (int e = 0; e < 6; ++e) put<T>(slots, at(0, e), fd.p[e]);
             put<T>(slots, at(0, 6), fd.force);
             put<T>(slots, at(0, 7), (double)fd.type);
+            if (fd.type == VFIK_FIELD_FUNNEL && !have_funnel) {
+                // the straight-line path's funnel block (used only when this funnel is the arm's one non-repeller entry)
+                have_funnel = true;
+                const double blk[12] = {fd.p[0], fd.p[1], fd.p[2], fd.p[3], fd.p[4], fd.p[5], fd.p[6], fd.p[7], fd.p[8], fd.p[9], fd.force, 1.0};
+                for (int e = 0; e < 12; ++e) put<T>(funnel, ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3), blk[e]);
+            }
             if (fd.type == VFIK_FIELD_REPELLER) {
-                const int pair = m >> 1, half = m & 1;
+                const int pair = mr >> 1, half = mr & 1;
+                ++mr;
                 for (int i = 0; i < 6; ++i) {
                     const int e = 6 * half + i;  // position in the pair's 12 scalars
                     put<T>(fast, ((size_t)(3 * pair + (e >> 2)) * n_arms + j) * 4 + (e & 3), i < 5 ? fd.p[i] : fd.force);
@@ -206,6 +220,8 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
             m += ns;
         }
         used[j] = m;
+        used_fast[j] = mr;
+        has_funnel[j] = have_funnel ? 1 : 0;
     }
 }
 
@@ -248,6 +264,9 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.sub8_max_batch_ns = h->sub8_max_batch_ns;
     a.n_simd = h->n_simd;
     a.arena = h->d_arena;
+    a.funnel = h->d_funnel;
+    a.slots_used_fast = h->slots_used_fast;
+    a.has_funnel = h->any_funnel;
     a.pers = h->pers;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
@@ -270,11 +289,19 @@ int upload_kconst(vfik_handle* h) {
 // which arms qualify for the kernel's straight-line repeller path
 int classify_arm(const vfik_field* f, int count) {
     int order = -1;
-    bool goal = false;
+    bool goal = false, funnel = false;
     for (int k = 0; k < count; ++k) {
         const vfik_field& fd = f[k];
         if (fd.type == VFIK_FIELD_NULL) continue;
         if (fd.type == VFIK_FIELD_ATTRACTOR && !goal) { goal = true; continue; }
+        if (fd.type == VFIK_FIELD_FUNNEL && !funnel) {
+            // one funnel attractor with small integer decay orders (object_feeder:277,279 sends 10 and 2): the straight-line
+            // path evaluates it from its own block
+            funnel = true;
+            const double oa = fd.p[7], od = fd.p[9];
+            if (!((double)(int)oa == oa) || oa < 0 || oa >= 128 || !((double)(int)od == od) || od < 0 || od >= 128) return -2;
+            continue;
+        }
         if (fd.type != VFIK_FIELD_REPELLER) return -2;
         const double o = fd.p[5];
         const int n = (int)o;
@@ -342,7 +369,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     h->Bpad = (batch + 63) / 64 * 64;
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
     {   // the state a lean launch reads, in one allocation whose layout the kernel can derive (vfik_kernel.h: arena layout)
-        const size_t sz_goal = 4 * quad_plane;
+        const size_t sz_goal = (4 + 3) * quad_plane;   // goal block + funnel block
         const size_t sz_kc = VFIK_KCONST_SLOT(vfik::kconst_bytes(n_joints));   // (+ slack inside: the kinematics block is copied in whole 1-KiB rows)
         const size_t sz_lv = (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float);
         const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
@@ -350,6 +377,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_sl, true)) return bail("alloc state arena");
         char* a0 = static_cast<char*>(h->d_arena);
         h->d_goal = a0;
+        h->d_funnel = a0 + 4 * quad_plane;
         h->d_kconst = a0 + sz_goal;
         h->d_lastvec = reinterpret_cast<float*>(a0 + sz_goal + sz_kc);
         h->d_slots_fast = a0 + sz_goal + sz_kc + sz_lv;
@@ -357,6 +385,8 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     }
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
     h->slots_per_arm.assign(B, 0);
+    h->fast_slots_per_arm.assign(B, 0);
+    h->arm_has_funnel.assign(B, 0);
     h->arm_order.assign(B, -1);
 #ifdef VFIK_STAMPS
     if (dev_alloc(h, (void**)&h->d_stamps, ((B + 63) / 64) * 10 * sizeof(unsigned long long), true)) return bail("alloc stamps");
@@ -565,16 +595,17 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         if (need > h->max_slots) return fail(VFIK_E_ARG, "arm %d needs %d slots, handle capacity is %d", first_arm + j, need, h->max_slots);
     }
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<char> goal, slots, fast;
-    std::vector<int> used(n_arms);
+    std::vector<char> goal, slots, fast, funnel, hasf(n_arms);
+    std::vector<int> used(n_arms), used_fast(n_arms);
     const int S = h->max_slots;
-    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used);
-    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used);
+    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf);
+    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf);
     const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
     char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
     // plane 3 = (present, slow-down, force, speedScale): the 4th component belongs to vfik_set_speed_scale
     HIP_TRY(hipMemcpy2DAsync(dg + 3 * pitch, qb, goal.data() + 3 * w, qb, 3 * h->esz, n_arms, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(h->d_funnel) + (size_t)first_arm * qb, pitch, funnel.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
     if (S > 0) {
         char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
@@ -584,9 +615,14 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int j = 0; j < n_arms; ++j) {
         h->slots_per_arm[first_arm + j] = used[j];
+        h->fast_slots_per_arm[first_arm + j] = used_fast[j];
+        h->arm_has_funnel[first_arm + j] = hasf[j];
         h->arm_order[first_arm + j] = classify_arm(fields + (size_t)j * max_fields, counts[j]);
     }
     h->slots_used = *std::max_element(h->slots_per_arm.begin(), h->slots_per_arm.end());
+    h->slots_used_fast = *std::max_element(h->fast_slots_per_arm.begin(), h->fast_slots_per_arm.end());
+    h->any_funnel = 0;
+    for (char f : h->arm_has_funnel) h->any_funnel |= f;
     int fo = -1;
     bool general = false;
     for (int o : h->arm_order) {
@@ -1180,6 +1216,12 @@ int vfik_debug_read_stamps(vfik_handle* h, unsigned long long* dst) {
 #endif
 
 int vfik_slots_in_use(vfik_handle* h) { return h ? h->slots_used : VFIK_E_ARG; }
+
+int vfik_field_path(vfik_handle* h) {
+    if (!h) return VFIK_E_ARG;
+    if (h->fast_order < 0) return 0;
+    return h->any_funnel ? 2 : 1;
+}
 
 int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {
     if (check_handle(h)) return VFIK_E_ARG;

@@ -19,6 +19,7 @@
 // Arithmetic is float64 whatever the io dtype (DESIGN.md "Precision").
 #include "vfik_kernel.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -765,15 +766,22 @@ template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr b
 template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = LEAN == 1 && !ROLL && FASTF; };
 #endif
 template <typename T, int NJ> struct ArenaLayout {
-    __host__ __device__ static long kconst_off(long Bpad) { return 4 * Bpad * 4 * (long)sizeof(T); }
+    __host__ __device__ static long funnel_off(long Bpad) { return 4 * Bpad * 4 * (long)sizeof(T); }
+    __host__ __device__ static long kconst_off(long Bpad) { return (4 + 3) * Bpad * 4 * (long)sizeof(T); }
     __host__ __device__ static long lastvec_off(long Bpad) { return kconst_off(Bpad) + VFIK_KCONST_SLOT(KTab<NJ>::OFFSET + 1024); }
     __host__ __device__ static long slots_fast_off(long Bpad) { return lastvec_off(Bpad) + (long)((NJ + 4) / 4) * Bpad * 16; }
 };
 
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false>
+// FUN = the straight-line field path with a FUNNEL BLOCK: besides goal + decay repellers an arm may carry one funnel attractor
+// (integer decay orders) -- the goalAndNormal scene of the object feeder (object_feeder:248-303: attractor + approach funnel +
+// near-goal repeller + obstacles), which handlers.go_cart with a normal produces.  Its 12 scalars travel like the goal block (3
+// quad planes, requested right behind it) and are evaluated straight-line behind the attractor; on the general path the same
+// scene cost the C3 batch 8.8 instead of 5.5 us (the funnel is a ~200-instruction dependent chain evaluated entry by entry).
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
-    static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7), "PERS: lean straight-line float launches only");
+    static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
+    static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
     KArgs a;
     if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
         a = KArgs{};
@@ -781,6 +789,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         a.q = a_in.q; a.qdot_out = a_in.qdot_out; a.status = a_in.status;
         const char* const base = static_cast<const char*>(a_in.base);
         a.goal = base;
+        a.funnel = base + ArenaLayout<T, NJ>::funnel_off(a_in.Bpad);
         a.kc = base + ArenaLayout<T, NJ>::kconst_off(a_in.Bpad);
         a.lastvec = reinterpret_cast<float*>(const_cast<char*>(base) + ArenaLayout<T, NJ>::lastvec_off(a_in.Bpad));
         a.slots_fast = base + ArenaLayout<T, NJ>::slots_fast_off(a_in.Bpad);
@@ -828,7 +837,9 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     const int lane = threadIdx.x & 63;
     // wave-uniform by construction; say so, or every LDS destination goes through a VGPR + readfirstlane
     // (LEAN launches run the straight-line path and touch only the head of the region: their waves are packed closer)
-    constexpr int REGION_BYTES = (LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);
+    constexpr int FUN_OFF = Stage<T>::lean_bytes(NJ);       // FUN: the funnel block's 3 rows sit behind the lean region
+    constexpr int NFUN = FUN ? 3 : 0;
+    constexpr int REGION_BYTES = ((LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ)) + NFUN * Stage<T>::QSTEP;
     char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * REGION_BYTES;
     // per-arm inputs (goal block, first-chunk slot quads, q) of the chunk being computed: the head of the region, or
     // (PERS, odd chunks of the wave) the second per-arm area behind the constants and the table
@@ -918,6 +929,11 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
+    if constexpr (FUN) {  // the funnel block, right behind the goal block: the goal's wait covers it
+        const char* fg = static_cast<const char*>(a.funnel) + (long)arm * QB;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stage_quad<T, NTL>(fg + k * planeB, region, FUN_OFF + k * Stage<T>::QSTEP);
+    }
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
@@ -942,7 +958,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         }
     };
     if constexpr (!PERS) {
-        VFIK_WAIT_VM((4 + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal and early slot requests may still be out)
+        VFIK_WAIT_VM((4 + NFUN + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal, funnel and early slot requests may still be out)
         STAMP(2);
         read_q();
     }
@@ -1336,6 +1352,32 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
             // a.goal_dist requested: the angle is needed whatever its size (cos_slow = -2 forces atan2)
             attractor(Rt, pt, GR, Gp, gq[13], gq[14], HOTK(rot_slow), a.goal_dist ? -2.0 : HOTK(cos_slow), gq[12] != 0.0, tot, sc, gdist);
         }
+    }
+    if constexpr (FUN) {
+        // type 5, funnel attractor (object_feeder:262-279), straight-line from its own block -- the arithmetic of eval_slot's funnel
+        // branch, an absent funnel masked by selects: w = p - o, perp = w - (w . a^) a^, phi = atan2(|perp|, w . a^),
+        // vector -perp^ min(1, (phi / cutAngle)^angleOrder) min(1, (cutDist / |w|)^distOrder)
+        double f[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) read_quad<T>(region, FUN_OFF + k * Stage<T>::QSTEP, lanec, f + 4 * k);
+        double an, ainv;
+        sqrt_rsqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5], an, ainv);
+        const bool on = f[11] != 0.0 && an > EPS_LEN;
+        const double ax = f[3] * ainv, ay = f[4] * ainv, az = f[5] * ainv;
+        const double wx = pt[0] - f[0], wy = pt[1] - f[1], wz = pt[2] - f[2];
+        const double along = wx * ax + wy * ay + wz * az;
+        const double ex = wx - along * ax, ey = wy - along * ay, ez = wz - along * az;
+        double P, Pinv, dist, dinv;
+        sqrt_rsqrt(ex * ex + ey * ey + ez * ez, P, Pinv);
+        sqrt_rsqrt(wx * wx + wy * wy + wz * wz, dist, dinv);
+        Pinv = P < D_FLOOR ? 1.0 / D_FLOOR : Pinv;
+        dinv = dist < D_FLOOR ? 1.0 / D_FLOOR : dinv;
+        const double phi = atan2_pos(P, on ? along : 1.0);
+        const double cutA = f[6];
+        const double ga = cutA > 0.0 ? fmin(1.0, pow_order(phi * rcp_nr(cutA > 0.0 ? cutA : 1.0), on ? f[7] : 1.0)) : 1.0;
+        const double gd = fmin(1.0, pow_order(f[8] * dinv, on ? f[9] : 1.0));
+        const double kf = on ? -f[10] * ga * gd * Pinv : 0.0;  // (a select: an absent funnel's block holds zeros, its terms may be NaN)
+        tot[0] += on ? ex * kf : 0.0; tot[1] += on ? ey * kf : 0.0; tot[2] += on ? ez * kf : 0.0;
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
     STAMP(4);
@@ -2405,10 +2447,23 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
 }
 
 template <typename T, int NJ, bool NS, bool PL>
-void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, int* sub8) {
+void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, int* sub8) {
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
     // one, the general path's code cost the straight-line launches 2.7 % (register allocation and layout).
-    const bool fastf = a.fast_order >= 0;
+    KArgs a = a_in;
+    bool fastf = a.fast_order >= 0;
+    // a funnel block in the batch (the goalAndNormal scene): the straight-line path has FUN variants for the lean single-cycle
+    // launches of PLAIN chains; every other launch of such a batch takes the general path
+    bool fun = false;
+    if (fastf && a.has_funnel) {
+        bool lean13 = false;
+        if constexpr (PL)
+            lean13 = (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.q_lo && !a.q_ref_out &&
+                     !a.q_out && a.n_cycles == 0;
+        if (lean13) fun = true;
+        else { fastf = false; a.fast_order = -1; }
+    }
+    if (fastf) a.slots_used = a.slots_used_fast;  // (the straight-line path counts the slots of the compact image)
     // LEAN launches touch only the head of the region.  They ask for no more than that while the launch is at most one
     // wave per SIMD (C5 -2 %, C3N -0.6 %, C3 +-0 at 65 536 arms); beyond, the full size keeps the launch in rounds of one
     // wave per SIMD -- with eight waves resident per CU a 131 072-arm launch took 12.5 instead of 11.0 us (two waves
@@ -2436,7 +2491,7 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
     if constexpr (PL && NJ <= (NS ? 7 : 8)) {
         // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
         // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
-        const bool served = fastf && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
+        const bool served = fastf && !fun && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
                             !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
                             (NS || (a.flags == 0 && !a.null_control));
         // Adopted where the same-box A/B wins (profiles/r03_latency_small_*.txt, 1 ... 4 096 arms): launches that publish the
@@ -2456,14 +2511,20 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         // with the next chunk's inputs in flight under the current chunk's arithmetic (cycle_kernel, PERS).  Two per-arm
         // areas per wave: lean_bytes + kin_off = 37.5 KB for 7 joints, four waves per CU.
         const long nchunks = (a.B + 63) / 64;
-        if (lean && !a.q_out && a.n_cycles == 0 && a.pers && nchunks > (long)a.n_simd) {
+        if (lean && !fun && !a.q_out && a.n_cycles == 0 && a.pers && nchunks > (long)a.n_simd) {
             const dim3 gp((unsigned)a.n_simd), bp(64);
             const size_t lds_p = Stage<T>::lean_bytes(NJ) + Stage<T>::kin_off(NJ);
             hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, true>), gp, bp, lds_p, stream, args_for<1, false, true>(a));
             return;
         }
     }
+    // (FUN launches: the lean region + the funnel block's three rows per wave; beyond one wave per SIMD the full region, as above)
+    const size_t lds_fun = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 3 * Stage<T>::QSTEP));
     if constexpr (PL) {
+        if (fun && lean && !a.q_out) {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, false, true>), grid, blk, lds_fun, stream, args_for<1, false, true>(a));
+            return;
+        }
         if (lean && !a.q_out) {
             // (chains of up to 7 joints: C3N -1 %; the 14-joint kernel got 10 % SLOWER with its flags fixed -- the
             // compiler then hoists the joint-limit task's constants over the whole kernel -- and keeps them run-time)
@@ -2492,6 +2553,10 @@ void launch_v(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t strea
         // publishing lean launches (LEAN 3): the straight-line path, no per-arm option, single cycle
         const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
                            !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
+        if (lean3 && fun) {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, -1, false, true>), grid, blk, lds_fun, stream, a);
+            return;
+        }
         if (lean3) {
             if constexpr (NS && NJ <= 7) {
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;

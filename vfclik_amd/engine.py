@@ -79,6 +79,7 @@ def load_library(path=None):
         "vfik_memcpy_d2h": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_size_t]),
         "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "vfik_slots_in_use": (C.c_int, [H]),
+        "vfik_field_path": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
         "vfik_host_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_host_free": (C.c_int, [H, C.c_void_p]),
@@ -229,6 +230,11 @@ class Engine:
     @property
     def slots_in_use(self):
         return self.lib.vfik_slots_in_use(self.h)
+
+    @property
+    def field_path(self):
+        """0 general, 1 straight-line (goal + decay repellers of one integer order), 2 straight-line with a funnel block."""
+        return self.lib.vfik_field_path(self.h)
 
     @property
     def device_bytes(self):
