@@ -267,9 +267,10 @@ long vfik_small_batch_launches(vfik_handle* h);
 int vfik_slots_in_use(vfik_handle* h);
 /* Which field path the handle's current field sets select for a cycle launch (decided when they are packed, vfik_set_fields):
  * 1 = straight-line: every arm is goal + decay repellers of one integer order (what object_feeder sends for point obstacles,
- * object_feeder:317-334); 2 = straight-line with a funnel block: as 1, and arms may carry ONE funnel attractor with integer
- * decay orders -- the goalAndNormal scene (object_feeder:248-303: attractor + approach funnel + near-goal repeller + obstacles);
- * 0 = general: anything else (hemispheres, further attractors, several funnels, fractional or mixed orders), entry by entry. */
+ * object_feeder:317-334); 2 = straight-line with an aux block: as 1, and arms may carry ONE funnel attractor and ONE hemisphere
+ * repeller with integer decay orders -- the goalAndNormal scene (object_feeder:248-303: attractor + approach funnel + near-goal
+ * repeller + obstacles) and a surface (ObstacleH, object_feeder:344-353);
+ * 0 = general: anything else (further attractors, several funnels or hemispheres, fractional or mixed orders), entry by entry. */
 int vfik_field_path(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);
 

@@ -685,11 +685,12 @@ def test_slot_counts_around_the_chunk_boundaries(env, robot, nobs):
     _compare(got, ref, TOL32, ("qdot_out", "status"))
 
 
-def _goal_and_normal_scene(env, chain, B, dt, n_obstacles, rng, funnel_share=1.0):
+def _goal_and_normal_scene(env, chain, B, dt, n_obstacles, rng, funnel_share=1.0, table_share=0.0):
     """What object_feeder sends for a goal with an approach vector (object_feeder:248-303): attractor (id 1), funnel attractor
-    (id 2, force 30, orders 10 / 2), near-goal repeller (id 3, 5 cm up the approach axis), then point obstacles (ids 4 ...)."""
+    (id 2, force 30, orders 10 / 2), near-goal repeller (id 3, 5 cm up the approach axis), then point obstacles (ids 4 ...) and,
+    for table_share of the arms, a table: a hemisphere repeller (ObstacleH, object_feeder:344-353: safe distance, order 5) behind them."""
     f = env.abi
-    w = env.synth.make_workload(chain, B, n_obstacles, seed=int(rng.integers(1 << 30)), io_dtype=dt, max_fields=3 + n_obstacles)
+    w = env.synth.make_workload(chain, B, n_obstacles, seed=int(rng.integers(1 << 30)), io_dtype=dt, max_fields=4 + n_obstacles)
     F = w["fields"]
     M = F.shape[1]
     # shift the obstacles behind the funnel and the near-goal repeller
@@ -705,10 +706,17 @@ def _goal_and_normal_scene(env, chain, B, dt, n_obstacles, rng, funnel_share=1.0
     F["p"][:, 2] = 0.0
     F["p"][:, 2, 0:3] = goal_p + 0.05 * axis
     F["p"][:, 2, 3:6] = [0.15 + 0.05, 0.001, 5.0]
+    k = 3 + n_obstacles
+    F["id"][:, k], F["type"][:, k], F["force"][:, k] = 40, f.FIELD_HEMISPHERE, -50.0
+    F["p"][:, k] = 0.0
+    F["p"][:, k, 0:3] = np.stack([rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-0.6, 0.1, B)], axis=1)
+    F["p"][:, k, 3:6] = np.stack([rng.normal(0, 0.1, B), rng.normal(0, 0.1, B), np.ones(B)], axis=1) * rng.uniform(0.5, 2.0, (B, 1))
+    F["p"][:, k, 6:8] = [0.05, 5.0]
     F["p"] = F["p"].astype(dt).astype(np.float64)
     w["nfields"][:] = M
     no_funnel = rng.uniform(size=B) >= funnel_share        # some arms: goal + obstacles only (type 0 leaves the entry empty)
     F["type"][no_funnel, 1] = f.FIELD_NULL
+    F["type"][rng.uniform(size=B) >= table_share, k] = f.FIELD_NULL
     return w
 
 
@@ -720,14 +728,16 @@ def _goal_and_normal_scene(env, chain, B, dt, n_obstacles, rng, funnel_share=1.0
     ("lwr_dual14", 4200, np.float32, TOL32, 7, 6),
     ("lwr", 64, np.float64, TOL64, 0, 0),           # funnel and near-goal repeller alone
 ])
-def test_goal_and_normal_scene_on_the_straight_line_path(env, robot, B, dt, tol, flags, nobs):
-    """handlers.go_cart with a normal -> object_feeder's goalAndNormal: the funnel travels in its own block and the scene stays on the
-    straight-line field path (vfik_field_path == 2); every output against the oracle, arms with and without a funnel in one batch."""
+@pytest.mark.parametrize("table_share", [0.0, 0.6])
+def test_goal_and_normal_scene_on_the_straight_line_path(env, robot, B, dt, tol, flags, nobs, table_share):
+    """handlers.go_cart with a normal -> object_feeder's goalAndNormal, with and without a table (ObstacleH): the funnel and the
+    hemisphere travel in the aux block and the scene stays on the straight-line field path (vfik_field_path == 2); every output
+    against the oracle, arms with and without a funnel / a table in one batch."""
     chain = env.robots.by_name(robot)
     rng = np.random.default_rng(B + nobs)
-    w = _goal_and_normal_scene(env, chain, B, dt, nobs, rng, funnel_share=0.8)
+    w = _goal_and_normal_scene(env, chain, B, dt, nobs, rng, funnel_share=0.8, table_share=table_share)
     params = env.abi.default_params(flags=flags)
-    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=4 + nobs, params=params)
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=5 + nobs, params=params)
     eng.set_small_batch_kernel(0)
     eng.set_fields(w["fields"], w["nfields"])
     assert eng.field_path == 2
@@ -782,5 +792,20 @@ def test_field_path_classification(env):
     F[1, 4]["p"][:8] = [0.2, -0.1, -0.5, 0.05, -0.02, 1.0, 0.05, 5.0]
     n[1] = 5
     eng.set_fields(F, n)
-    assert eng.field_path == 0                     # a hemisphere anywhere: general
+    assert eng.field_path == 2                     # one hemisphere with an integer order: the aux block as well
+    F[1, 4]["p"][7] = 4.5
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # fractional order: general
+    F[1, 4]["p"][7] = 5.0
+    F[1, 5] = F[1, 4]
+    F[1, 5]["id"] = 10
+    n[1] = 6
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # a second hemisphere: general
+    n[1] = 5
+    F[2, 4]["id"], F[2, 4]["type"], F[2, 4]["force"] = 11, f.FIELD_ATTRACTOR, 1.0
+    F[2, 4]["p"][:17] = F[2, 0]["p"][:17]
+    n[2] = 5
+    eng.set_fields(F, n)
+    assert eng.field_path == 0                     # a second attractor: general
     eng.close()

@@ -42,6 +42,13 @@ F["p"][:, 7, 0:3] = F["p"][:, 0, [3, 7, 11]] - 0.05 * F["p"][:, 0, [2, 6, 10]]
 F["p"][:, 7, 3:6] = [0.05, 0.001, 5.0]
 w["nfields"][:] = 8
 run("goalAndNormal + 5 obstacles", w, 10)
+# the same scene over a table (ObstacleH, object_feeder:344-353): one hemisphere repeller more, in place of the fifth obstacle
+F["id"][:, 5], F["type"][:, 5], F["force"][:, 5] = 40, 4, -50.0
+F["p"][:, 5] = 0.0
+F["p"][:, 5, 0:8] = [0.0, 0.0, -0.3, 0.02, -0.01, 1.0, 0.05, 5.0]
+run("goalAndNormal + 4 obst. + table", w, 11)
+F["p"][0, 5, 7] = 4.5      # one arm's table with a fractional order: the whole batch on the general path
+run("... on the general path", w, 11)
 chain = robots.lwr_dual14()
 w = synth.make_workload(chain, B, 16, seed=1, io_dtype=np.float32)
 

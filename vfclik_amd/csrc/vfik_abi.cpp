@@ -73,7 +73,7 @@ struct vfik_handle {
     // device state
     void* d_arena = nullptr;   // [goal | kconst | lastvec | slots_fast | slots]: d_goal, d_kconst, d_lastvec, d_slots_fast, d_slots point into it
     void* d_goal = nullptr;    // 4 quad planes
-    void* d_funnel = nullptr;  // 3 quad planes: the arm's funnel attractor on the straight-line path (vfik_kernel.h)
+    void* d_funnel = nullptr;  // aux block, 6 quad planes: the arm's funnel attractor (3) and hemisphere repeller (3) on the straight-line path (vfik_kernel.h)
     void* d_slots = nullptr;   // 2*S quad planes
     void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
     void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
@@ -164,7 +164,7 @@ template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
                  std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used,
                  std::vector<char>& funnel, std::vector<int>& used_fast, std::vector<char>& has_funnel) {
-    funnel.assign((size_t)3 * n_arms * 4 * sizeof(T), 0);
+    funnel.assign((size_t)6 * n_arms * 4 * sizeof(T), 0);  // aux block: funnel planes 0..2, hemisphere planes 3..5
     goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
     slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
     // compact image: a decay repeller needs 6 of its slot's 8 scalars (x y z radius safe | force; the decay order is
@@ -177,7 +177,7 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
         order.resize(counts[j]);
         for (int k = 0; k < counts[j]; ++k) order[k] = k;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f[a].id < f[b].id; });
-        bool have_goal = false, have_funnel = false;
+        bool have_goal = false, have_funnel = false, have_hemi = false;
         int m = 0, mr = 0;  // general slots used; compact-image slots used (repellers only, packed densely)
         auto gq = [&](int e) { return ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3); };
         for (int k : order) {
@@ -202,6 +202,12 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
                 const double blk[12] = {fd.p[0], fd.p[1], fd.p[2], fd.p[3], fd.p[4], fd.p[5], fd.p[6], fd.p[7], fd.p[8], fd.p[9], fd.force, 1.0};
                 for (int e = 0; e < 12; ++e) put<T>(funnel, ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3), blk[e]);
             }
+            if (fd.type == VFIK_FIELD_HEMISPHERE && !have_hemi) {
+                // ... and the hemisphere block (object_feeder:344-353, ObstacleH: a surface with its normal): x y z nx | ny nz safe order | force present
+                have_hemi = true;
+                const double blk[12] = {fd.p[0], fd.p[1], fd.p[2], fd.p[3], fd.p[4], fd.p[5], fd.p[6], fd.p[7], fd.force, 1.0, 0.0, 0.0};
+                for (int e = 0; e < 12; ++e) put<T>(funnel, ((size_t)(3 + (e >> 2)) * n_arms + j) * 4 + (e & 3), blk[e]);
+            }
             if (fd.type == VFIK_FIELD_REPELLER) {
                 const int pair = mr >> 1, half = mr & 1;
                 ++mr;
@@ -221,7 +227,7 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
         }
         used[j] = m;
         used_fast[j] = mr;
-        has_funnel[j] = have_funnel ? 1 : 0;
+        has_funnel[j] = (have_funnel || have_hemi) ? 1 : 0;
     }
 }
 
@@ -289,7 +295,7 @@ int upload_kconst(vfik_handle* h) {
 // which arms qualify for the kernel's straight-line repeller path
 int classify_arm(const vfik_field* f, int count) {
     int order = -1;
-    bool goal = false, funnel = false;
+    bool goal = false, funnel = false, hemi = false;
     for (int k = 0; k < count; ++k) {
         const vfik_field& fd = f[k];
         if (fd.type == VFIK_FIELD_NULL) continue;
@@ -300,6 +306,12 @@ int classify_arm(const vfik_field* f, int count) {
             funnel = true;
             const double oa = fd.p[7], od = fd.p[9];
             if (!((double)(int)oa == oa) || oa < 0 || oa >= 128 || !((double)(int)od == od) || od < 0 || od >= 128) return -2;
+            continue;
+        }
+        if (fd.type == VFIK_FIELD_HEMISPHERE && !hemi) {  // one hemisphere repeller with a small integer decay order (object_feeder:353 sends 5)
+            hemi = true;
+            const double oh = fd.p[7];
+            if (!((double)(int)oh == oh) || oh < 0 || oh >= 128) return -2;
             continue;
         }
         if (fd.type != VFIK_FIELD_REPELLER) return -2;
@@ -369,7 +381,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     h->Bpad = (batch + 63) / 64 * 64;
     const size_t quad_plane = (size_t)h->Bpad * 4 * h->esz;
     {   // the state a lean launch reads, in one allocation whose layout the kernel can derive (vfik_kernel.h: arena layout)
-        const size_t sz_goal = (4 + 3) * quad_plane;   // goal block + funnel block
+        const size_t sz_goal = (4 + 6) * quad_plane;   // goal block + aux block (funnel, hemisphere)
         const size_t sz_kc = VFIK_KCONST_SLOT(vfik::kconst_bytes(n_joints));   // (+ slack inside: the kinematics block is copied in whole 1-KiB rows)
         const size_t sz_lv = (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float);
         const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
@@ -605,7 +617,7 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
     // plane 3 = (present, slow-down, force, speedScale): the 4th component belongs to vfik_set_speed_scale
     HIP_TRY(hipMemcpy2DAsync(dg + 3 * pitch, qb, goal.data() + 3 * w, qb, 3 * h->esz, n_arms, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(h->d_funnel) + (size_t)first_arm * qb, pitch, funnel.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(h->d_funnel) + (size_t)first_arm * qb, pitch, funnel.data(), w, w, 6, hipMemcpyHostToDevice, h->stream));
     if (S > 0) {
         char* ds = static_cast<char*>(h->d_slots) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));

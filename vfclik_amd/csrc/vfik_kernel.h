@@ -22,6 +22,7 @@ namespace vfik {
 //   goal                  4 planes    frame rows 0,1,2 | (present, slow-down, force, speedScale of the arm)
 //   funnel                3 planes    the arm's funnel attractor (object_feeder:262-279: the approach cone of a goal with a normal), if it is
 //                                     the only non-repeller entry of the set: (x y z ax | ay az cutAngle angleOrder | cutDist distOrder force present)
+//   hemisphere            3 planes    likewise the arm's ONE hemisphere repeller (object_feeder:344-353): (x y z nx | ny nz safeDist order | force present - -)
 //   slots_fast            3 ceil(S/2) planes  decay repellers only, two slots in three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1);
 //                                     what the straight-line field path reads (24 instead of 32 bytes a slot at float I/O)
 //   slots                 2S planes   slot m = planes 2m, 2m+1 = (p0 p1 p2 p3 | p4 p5 force type);
@@ -125,15 +126,16 @@ struct KArgs {
     int sub8_max_batch_ns;       // ... with the nullspace module, qdot_out / status only
     int sub8_max_batch_full;     // ... when the launch asks for more than qdot_out (the rows the per-arm processes publish every cycle)
     int n_simd;                  // SIMDs of the device (4 per CU): launches of at most that many waves are one wave per SIMD
-    const void* funnel;          // funnel block: 3 quad planes (x y z ax | ay az cutAngle angleOrder | cutDist distOrder force present), or unused
+    const void* funnel;          // aux block, 6 quad planes: funnel (x y z ax | ay az cutAngle angleOrder | cutDist distOrder force present) and
+                                 // hemisphere (x y z nx | ny nz safeDist order | force present - -), or unused
     int slots_used_fast;         // slots of the COMPACT repeller image in use (an arm's funnel is not a slot there)
-    int has_funnel;              // some arm's field set has a funnel attractor (straight-line path: the FUN kernel variants)
+    int has_funnel;              // some arm's field set has a funnel attractor or a hemisphere repeller (straight-line path: the FUN kernel variants)
     const void* arena;           // the handle's state arena [goal | kconst | lastvec | slots_fast | slots] (arena_layout), or NULL
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
 };
 
 // The per-handle device state a LEAN launch reads lives in ONE allocation with offsets that follow from (io type, joints, Bpad):
-//   [goal: 4 quad planes | funnel: 3 quad planes | kconst: KCONST_SLOT(nj) bytes | lastvec: (nj + 4) / 4 planes of 16 B | slots_fast ... | slots ...]
+//   [goal: 4 quad planes | aux (funnel 3, hemisphere 3): 6 quad planes | kconst: KCONST_SLOT(nj) bytes | lastvec: (nj + 4) / 4 planes of 16 B | slots_fast ... | slots ...]
 // so that such a launch's kernarg is one base pointer + the io pointers (KLean, 56 bytes) instead of the 340-byte KArgs: what a
 // launch costs the HOST grows with its kernarg (tools/ubench_launch: 32-64 B 2.8 us, 336 B 3.9 us on a slow host), and at a
 // 5-us launch period the enqueue loop is never far from being the bottleneck.

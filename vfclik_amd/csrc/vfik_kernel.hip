@@ -767,15 +767,16 @@ template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr b
 #endif
 template <typename T, int NJ> struct ArenaLayout {
     __host__ __device__ static long funnel_off(long Bpad) { return 4 * Bpad * 4 * (long)sizeof(T); }
-    __host__ __device__ static long kconst_off(long Bpad) { return (4 + 3) * Bpad * 4 * (long)sizeof(T); }
+    __host__ __device__ static long kconst_off(long Bpad) { return (4 + 6) * Bpad * 4 * (long)sizeof(T); }
     __host__ __device__ static long lastvec_off(long Bpad) { return kconst_off(Bpad) + VFIK_KCONST_SLOT(KTab<NJ>::OFFSET + 1024); }
     __host__ __device__ static long slots_fast_off(long Bpad) { return lastvec_off(Bpad) + (long)((NJ + 4) / 4) * Bpad * 16; }
 };
 
-// FUN = the straight-line field path with a FUNNEL BLOCK: besides goal + decay repellers an arm may carry one funnel attractor
-// (integer decay orders) -- the goalAndNormal scene of the object feeder (object_feeder:248-303: attractor + approach funnel +
-// near-goal repeller + obstacles), which handlers.go_cart with a normal produces.  Its 12 scalars travel like the goal block (3
-// quad planes, requested right behind it) and are evaluated straight-line behind the attractor; on the general path the same
+// FUN = the straight-line field path with an AUX BLOCK: besides goal + decay repellers an arm may carry one funnel attractor and one
+// hemisphere repeller (integer decay orders) -- the goalAndNormal scene of the object feeder (object_feeder:248-303: attractor + approach funnel +
+// near-goal repeller + obstacles), which handlers.go_cart with a normal produces, and a surface (ObstacleH, object_feeder:344-353).
+// Their 12 + 10 scalars travel like the goal block (6 quad planes, requested right behind it) and are evaluated straight-line
+// behind the attractor; on the general path the same
 // scene cost the C3 batch 8.8 instead of 5.5 us (the funnel is a ~200-instruction dependent chain evaluated entry by entry).
 template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -837,8 +838,8 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     const int lane = threadIdx.x & 63;
     // wave-uniform by construction; say so, or every LDS destination goes through a VGPR + readfirstlane
     // (LEAN launches run the straight-line path and touch only the head of the region: their waves are packed closer)
-    constexpr int FUN_OFF = Stage<T>::lean_bytes(NJ);       // FUN: the funnel block's 3 rows sit behind the lean region
-    constexpr int NFUN = FUN ? 3 : 0;
+    constexpr int FUN_OFF = Stage<T>::lean_bytes(NJ);       // FUN: the aux block's rows sit behind the lean region
+    constexpr int NFUN = FUN ? 6 : 0;                       // (funnel 3 + hemisphere 3)
     constexpr int REGION_BYTES = ((LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ)) + NFUN * Stage<T>::QSTEP;
     char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * REGION_BYTES;
     // per-arm inputs (goal block, first-chunk slot quads, q) of the chunk being computed: the head of the region, or
@@ -932,7 +933,7 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     if constexpr (FUN) {  // the funnel block, right behind the goal block: the goal's wait covers it
         const char* fg = static_cast<const char*>(a.funnel) + (long)arm * QB;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stage_quad<T, NTL>(fg + k * planeB, region, FUN_OFF + k * Stage<T>::QSTEP);
+        for (int k = 0; k < NFUN; ++k) stage_quad<T, NTL>(fg + k * planeB, region, FUN_OFF + k * Stage<T>::QSTEP);
     }
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
@@ -1378,6 +1379,20 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
         const double gd = fmin(1.0, pow_order(f[8] * dinv, on ? f[9] : 1.0));
         const double kf = on ? -f[10] * ga * gd * Pinv : 0.0;  // (a select: an absent funnel's block holds zeros, its terms may be NaN)
         tot[0] += on ? ex * kf : 0.0; tot[1] += on ? ey * kf : 0.0; tot[2] += on ? ez * kf : 0.0;
+        // type 4, hemisphere repeller (object_feeder:344-353: a surface with its normal), from the block behind the funnel's:
+        // h = (p - o) . n^, vector -n^ min((safe / max(h, floor))^order, cap) -- eval_slot's hemisphere branch, masked likewise
+        double g[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) read_quad<T>(region, FUN_OFF + (3 + k) * Stage<T>::QSTEP, lanec, g + 4 * k);
+        if (__any(g[9] != 0.0)) {  // (a wave without a table skips the chain: wave-uniform)
+            double nn, ninv;
+            sqrt_rsqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5], nn, ninv);
+            const bool hon = g[9] != 0.0 && nn > EPS_LEN;
+            const double hh = ((pt[0] - g[0]) * g[3] + (pt[1] - g[1]) * g[4] + (pt[2] - g[2]) * g[5]) * ninv;
+            const double hmag = fmin(pow_order(g[6] * rcp_nr(fmax(hon ? hh : 1.0, D_FLOOR)), hon ? g[7] : 1.0), MAG_CAP);
+            const double kh = hon ? -g[8] * hmag * ninv : 0.0;
+            tot[0] += hon ? g[3] * kh : 0.0; tot[1] += hon ? g[4] * kh : 0.0; tot[2] += hon ? g[5] * kh : 0.0;
+        }
     }
     PIN_ARR(tot, 6); PIN_ARR(sc, 2);
     STAMP(4);
@@ -2518,8 +2533,8 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             return;
         }
     }
-    // (FUN launches: the lean region + the funnel block's three rows per wave; beyond one wave per SIMD the full region, as above)
-    const size_t lds_fun = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 3 * Stage<T>::QSTEP));
+    // (FUN launches: the lean region + the aux block's six rows per wave; beyond one wave per SIMD the full region, as above)
+    const size_t lds_fun = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
     if constexpr (PL) {
         if (fun && lean && !a.q_out) {
             hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, false, true>), grid, blk, lds_fun, stream, args_for<1, false, true>(a));

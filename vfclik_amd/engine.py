@@ -233,7 +233,7 @@ class Engine:
 
     @property
     def field_path(self):
-        """0 general, 1 straight-line (goal + decay repellers of one integer order), 2 straight-line with a funnel block."""
+        """0 general, 1 straight-line (goal + decay repellers of one integer order), 2 straight-line with an aux block (one funnel and / or one hemisphere per arm)."""
         return self.lib.vfik_field_path(self.h)
 
     @property
