@@ -1,6 +1,7 @@
-"""Batches beyond one wave per SIMD take the persistent launch (cycle_kernel, PERS: one wave per SIMD striding over the
-64-arm chunks, the next chunk's inputs in flight into a second LDS area).  Parity against the oracle and against the
-launch in rounds (VFIK_PERSISTENT=0) on ragged batch sizes: waves with one, two and three chunks, a partial last chunk."""
+"""Batches beyond one wave per SIMD: the two-waves-per-SIMD build of the lean launch (cycle_kernel, WAVES 2: the default there) and
+the persistent launch (cycle_kernel, PERS, VFIK_PERSISTENT=1: one wave per SIMD striding over the 64-arm chunks, the next chunk's
+inputs in flight into a second LDS area).  Parity against the oracle and against the launch in rounds of one wave per SIMD
+(VFIK_TWO_WAVES=0) on ragged batch sizes: waves with one, two and three chunks, a partial last chunk."""
 import os
 
 import numpy as np
@@ -25,16 +26,22 @@ def env():
     return e
 
 
-def _engine(env, chain, B, nobs, params, persistent):
-    old = os.environ.get("VFIK_PERSISTENT")
-    os.environ["VFIK_PERSISTENT"] = "1" if persistent else "0"
+MODES = ("rounds", "two", "pers")
+
+
+def _engine(env, chain, B, nobs, params, mode):
+    """A handle whose big lean launches go in rounds of one wave per SIMD, as two waves per SIMD, or persistent."""
+    want = {"VFIK_PERSISTENT": "1" if mode == "pers" else "0", "VFIK_TWO_WAVES": "1" if mode == "two" else "0"}
+    old = {k: os.environ.get(k) for k in want}
+    os.environ.update(want)
     try:
         eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=max(1, nobs), params=params)
     finally:
-        if old is None:
-            del os.environ["VFIK_PERSISTENT"]
-        else:
-            os.environ["VFIK_PERSISTENT"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     return eng
 
 
@@ -45,29 +52,47 @@ def test_persistent_launch_matches_oracle_and_rounds(env, B, nobs):
     w = env.synth.make_workload(chain, B, nobs, seed=21, io_dtype=np.float32)
     ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out", "status"))
     outs = {}
-    for pers in (True, False):
-        eng = _engine(env, chain, B, nobs, params, pers)
+    for mode in MODES:
+        eng = _engine(env, chain, B, nobs, params, mode)
         eng.set_fields(w["fields"], w["nfields"])
-        outs[pers] = eng.step_host(w["q"], want=("qdot_out", "status"))
+        outs[mode] = eng.step_host(w["q"], want=("qdot_out", "status"))
         eng.close()
-    for pers in (True, False):
-        err = np.abs(outs[pers]["qdot_out"].astype(np.float64) - ref["qdot_out"])
-        assert err.max() < 1e-6, (pers, float(err.max()), int(np.argmax(err.max(axis=1))))
-        assert np.array_equal(outs[pers]["status"], ref["status"])
-    # same arithmetic in both launches (another schedule): equal to rounding of the float32 store
-    assert np.abs(outs[True]["qdot_out"] - outs[False]["qdot_out"]).max() < 1e-6
+    for mode in MODES:
+        err = np.abs(outs[mode]["qdot_out"].astype(np.float64) - ref["qdot_out"])
+        assert err.max() < 1e-6, (mode, float(err.max()), int(np.argmax(err.max(axis=1))))
+        assert np.array_equal(outs[mode]["status"], ref["status"])
+    # same arithmetic in every launch (another schedule): equal to rounding of the float32 store
+    assert np.abs(outs["pers"]["qdot_out"] - outs["rounds"]["qdot_out"]).max() < 1e-6
+    assert np.abs(outs["two"]["qdot_out"] - outs["rounds"]["qdot_out"]).max() < 1e-6
 
 
-def test_persistent_launch_with_the_nullspace_module_keeps_its_state(env):
+@pytest.mark.parametrize("robot,flags", [("powercube6", 0), ("powercube6", 7), ("lwr", 7)])
+def test_two_waves_build_of_the_other_lean_variants(env, robot, flags):
+    """The 6-joint chain and the joint-limit-task flag set through the two-waves-per-SIMD build, 70 000 arms."""
+    chain = env.robots.by_name(robot)
+    params = env.abi.default_params(flags=flags)
+    B = 70000 + 33
+    w = env.synth.make_workload(chain, B, 5, seed=23, io_dtype=np.float32)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out", "status"))
+    eng = _engine(env, chain, B, 5, params, "two")
+    eng.set_fields(w["fields"], w["nfields"])
+    got = eng.step_host(w["q"], want=("qdot_out", "status"))
+    eng.close()
+    assert np.abs(got["qdot_out"].astype(np.float64) - ref["qdot_out"]).max() < 2e-6
+    assert np.array_equal(got["status"], ref["status"])
+
+
+@pytest.mark.parametrize("mode", ["two", "pers"])
+def test_big_launch_with_the_nullspace_module_keeps_its_state(env, mode):
     """The default process set (nullspace + mixer) at 150 000 arms, three cycles: the sign memory of every arm advances
-    through the persistent launch exactly as through the oracle's state."""
+    through the two-waves / the persistent launch exactly as through the oracle's state."""
     chain = env.robots.lwr()
     f = env.abi
     params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER)
     B = 150000 + 13
     w = env.synth.make_workload(chain, B, 4, seed=22, io_dtype=np.float32)
     rng = np.random.default_rng(5)
-    eng = _engine(env, chain, B, 4, params, True)
+    eng = _engine(env, chain, B, 4, params, mode)
     eng.set_fields(w["fields"], w["nfields"])
     import torch
     q = w["q"].copy()
@@ -76,7 +101,7 @@ def test_persistent_launch_with_the_nullspace_module_keeps_its_state(env):
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     for t in range(3):
         q32 = q.astype(np.float32)
-        # lean device-pointer launch (qdot_out + status only: what takes the persistent kernel)
+        # lean device-pointer launch (qdot_out + status only: what takes these kernels)
         qd = torch.from_numpy(q32).cuda()
         out = torch.zeros(B, chain.n, dtype=torch.float32, device="cuda")
         st = torch.zeros(B, dtype=torch.int32, device="cuda")

@@ -64,6 +64,7 @@ struct vfik_handle {
     // 41.3 / 39.5 -- the wave is bound by its float64 instruction issue, not by the waits the prefetch removes
     // (profiles/r03_batch_scaling.txt).
     int pers = 0;
+    int waves2 = 1;
     size_t esz = 4;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -274,6 +275,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.slots_used_fast = h->slots_used_fast;
     a.has_funnel = h->any_funnel;
     a.pers = h->pers;
+    a.waves2 = h->waves2;
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -370,6 +372,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     }
     if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = h->sub8_max_batch_full = h->sub8_max_batch_ns = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VFIK_TWO_WAVES")) h->waves2 = std::atoi(e) != 0;
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");

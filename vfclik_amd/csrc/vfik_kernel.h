@@ -131,6 +131,7 @@ struct KArgs {
     int slots_used_fast;         // slots of the COMPACT repeller image in use (an arm's funnel is not a slot there)
     int has_funnel;              // some arm's field set has a funnel attractor or a hemisphere repeller (straight-line path: the FUN kernel variants)
     const void* arena;           // the handle's state arena [goal | kconst | lastvec | slots_fast | slots] (arena_layout), or NULL
+    int waves2;                  // 1: lean straight-line float launches of more than n_simd waves take the two-waves-per-SIMD build (VFIK_TWO_WAVES=0: never)
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
 };
 

@@ -778,11 +778,15 @@ template <typename T, int NJ> struct ArenaLayout {
 // Their 12 + 10 scalars travel like the goal block (6 quad planes, requested right behind it) and are evaluated straight-line
 // behind the attractor; on the general path the same
 // scene cost the C3 batch 8.8 instead of 5.5 us (the funnel is a ~200-instruction dependent chain evaluated entry by entry).
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// WAVES = 2: the same lean launch compiled for TWO waves per SIMD (at most 256 registers a lane; with float I/O two blocks' lean
+// regions, 2 x 79 KB, fit a CU's LDS), for batches beyond one wave per SIMD: the second wave issues into the first one's dependency
+// stalls -- 131 072 arms 10.3 -> 9.0 us, 524 288 arms 38.3 -> 34.6 us, same box (profiles/r03_batch_scaling.txt).
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
+    static_assert(WAVES == 1 || (WAVES == 2 && LEAN == 1 && FASTF && PLAIN && !ROLL && !PERS && !FUN && sizeof(T) == 4 && NJ <= 7), "WAVES 2: lean straight-line float launches only");
     KArgs a;
     if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
         a = KArgs{};
@@ -2543,6 +2547,20 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         if (lean && !a.q_out) {
             // (chains of up to 7 joints: C3N -1 %; the 14-joint kernel got 10 % SLOWER with its flags fixed -- the
             // compiler then hoists the joint-limit task's constants over the whole kernel -- and keeps them run-time)
+            if constexpr (sizeof(T) == 4 && NJ <= 7) {
+                // beyond one wave per SIMD: the two-waves-per-SIMD build, two blocks' lean regions resident per CU
+                if (a.waves2 && (long)grid.x * (blk.x / 64) > (long)a.n_simd) {
+                    const size_t lds2 = (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ);
+                    constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
+                    if (NS && a.flags == (unsigned)NSMIX)
+                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NS ? NSMIX : -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                    else if (NS && a.flags == (unsigned)NSJLMIX)
+                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NS ? NSJLMIX : -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                    else
+                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                    return;
+                }
+            }
             if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
