@@ -167,7 +167,8 @@ def kernel_name(io_name, n, flags, batch, sub8, full=False):
         cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
         return "vfik::cycle_kernel<%s,%d,%s,true,false,true,3,%d>" % (t, n, "true" if flags & 1 else "false", cf)
     cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
-    return "vfik::cycle_kernel<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
+    # (the lean variants take their ten arguments as scalars, preloaded into SGPRs: cycle_kernel_s)
+    return "vfik::cycle_kernel_s<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
 
 
 def pctl(xs, p):

@@ -231,6 +231,8 @@ def test_profile_digest_parses_kernel_names():
     n1 = "void vfik::(anonymous namespace)::cycle_kernel<float, 7, false, true, false, true, 1, -1, false>(std::conditional<SmallArgs<1, false, true>::value, vfik::KLean, vfik::KArgs>::type)"
     assert m.kernel_of(n1) == "cycle_kernel<float, 7, false, true, false, true, 1, -1, false>"
     assert m.kernel_of("void vfik::(anonymous namespace)::cycle_sub8_kernel<double, 7, true>(vfik::KArgs)") == "cycle_sub8_kernel<double, 7, true>"
+    n2 = "void vfik::(anonymous namespace)::cycle_kernel_s<float, 7, false, true, false, true, 1, -1, false, false, 1>(void const*, void const*, void*, int*, int, int, int, int, unsigned int, int)"
+    assert m.kernel_of(n2) == "cycle_kernel_s<float, 7, false, true, false, true, 1, -1, false, false, 1>"
     import json
     t = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     assert all(v["kernel"].startswith("cycle_") for v in t.values())

@@ -64,6 +64,8 @@ struct vfik_handle {
     // 41.3 / 39.5 -- the wave is bound by its float64 instruction issue, not by the waits the prefetch removes
     // (profiles/r03_batch_scaling.txt).
     int pers = 0;
+    // What pays there instead: the lean kernels compiled for two waves per SIMD (cycle_kernel WAVES = 2; float I/O, chains of up to 7
+    // joints): 131 072 arms 10.4 -> 9.1 us, 524 288 38.4 -> 33.4 (same file).  VFIK_TWO_WAVES=0 keeps the rounds of one wave per SIMD.
     int waves2 = 1;
     size_t esz = 4;
     hipStream_t stream = nullptr;

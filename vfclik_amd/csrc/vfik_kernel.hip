@@ -781,9 +781,9 @@ template <typename T, int NJ> struct ArenaLayout {
 // WAVES = 2: the same lean launch compiled for TWO waves per SIMD (at most 256 registers a lane; with float I/O two blocks' lean
 // regions, 2 x 79 KB, fit a CU's LDS), for batches beyond one wave per SIMD: the second wave issues into the first one's dependency
 // stalls -- 131 072 arms 10.3 -> 9.0 us, 524 288 arms 38.3 -> 34.6 us, same box (profiles/r03_batch_scaling.txt).
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES>
+__device__ __forceinline__ void
+cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type& a_in) {
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
     static_assert(WAVES == 1 || (WAVES == 2 && LEAN == 1 && FASTF && PLAIN && !ROLL && !PERS && !FUN && sizeof(T) == 4 && NJ <= 7), "WAVES 2: lean straight-line float launches only");
@@ -1950,6 +1950,26 @@ cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value
     }  // chunks of this wave (PERS)
 }
 
+// The kernel proper: the body above behind an argument block (KArgs, or KLean for the lean single-cycle straight-line variants) ...
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(a_in);
+}
+// ... or, for the KLean variants, behind KLean's ten members as SCALAR kernel arguments: those the command processor can preload into
+// the wave's SGPRs at dispatch (-amdgpu-kernarg-preload-count, Makefile; an argument block passed by value is never preloaded), which
+// takes the scalar-load round trip of the kernarg out of every wave's prologue.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+cycle_kernel_s(const void* base, const void* q, void* qdot_out, int* status, int B, int Bpad, int slots_used, int fast_order, unsigned flags, int block) {
+    static_assert(SmallArgs<LEAN, ROLL, FASTF>::value, "scalar arguments: the KLean variants");
+    KLean k;
+    k.base = base; k.q = q; k.qdot_out = qdot_out; k.status = status;
+    k.B = B; k.Bpad = Bpad; k.slots_used = slots_used; k.fast_order = fast_order; k.flags = flags; k.block = block;
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(k);
+}
+
+
 // CommandMixer.read's weighted sum alone (command_mixer.py:78-82): out = sum_k cmd[k] * w[k], left to
 // right from 0.0, multiply and add rounded separately (what CPython does).
 template <typename T>
@@ -2465,6 +2485,20 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
     }
 }
 
+#ifndef VFIK_SCALAR_KERNARG
+#define VFIK_SCALAR_KERNARG 1
+#endif
+// Launch of a KLean variant (lean, single cycle, straight-line field path): scalar kernel arguments, or the argument block
+template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+void launch_lean(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    if constexpr (SmallArgs<1, false, true>::value && VFIK_SCALAR_KERNARG) {
+        hipLaunchKernelGGL((cycle_kernel_s<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out, a.status,
+                           a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block);
+    } else {
+        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES>), grid, blk, lds, stream, args_for<1, false, true>(a));
+    }
+}
+
 template <typename T, int NJ, bool NS, bool PL>
 void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, int* sub8) {
     // FASTF: the straight-line repeller path and the general field path are separate kernels -- compiled into
@@ -2533,7 +2567,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         if (lean && !fun && !a.q_out && a.n_cycles == 0 && a.pers && nchunks > (long)a.n_simd) {
             const dim3 gp((unsigned)a.n_simd), bp(64);
             const size_t lds_p = Stage<T>::lean_bytes(NJ) + Stage<T>::kin_off(NJ);
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, true>), gp, bp, lds_p, stream, args_for<1, false, true>(a));
+            launch_lean<T, NJ, NS, PL, -1, true>(a, gp, bp, lds_p, stream);
             return;
         }
     }
@@ -2541,7 +2575,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
     const size_t lds_fun = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
     if constexpr (PL) {
         if (fun && lean && !a.q_out) {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, false, true>), grid, blk, lds_fun, stream, args_for<1, false, true>(a));
+            launch_lean<T, NJ, NS, PL, -1, false, true>(a, grid, blk, lds_fun, stream);
             return;
         }
         if (lean && !a.q_out) {
@@ -2553,26 +2587,26 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                     const size_t lds2 = (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ);
                     constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                     if (NS && a.flags == (unsigned)NSMIX)
-                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NS ? NSMIX : -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                        launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2>(a, grid, blk, lds2, stream);
                     else if (NS && a.flags == (unsigned)NSJLMIX)
-                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NS ? NSJLMIX : -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                        launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2>(a, grid, blk, lds2, stream);
                     else
-                        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, -1, false, false, 2>), grid, blk, lds2, stream, args_for<1, false, true>(a));
+                        launch_lean<T, NJ, NS, PL, -1, false, false, 2>(a, grid, blk, lds2, stream);
                     return;
                 }
             }
             if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSMIX>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
+                    launch_lean<T, NJ, NS, PL, NSMIX>(a, grid, blk, lds_lean, stream);
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, NSJLMIX>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
+                    launch_lean<T, NJ, NS, PL, NSJLMIX>(a, grid, blk, lds_lean, stream);
                     return;
                 }
             }
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1>), grid, blk, lds_lean, stream, args_for<1, false, true>(a));
+            launch_lean<T, NJ, NS, PL>(a, grid, blk, lds_lean, stream);
             return;
         }
         if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
