@@ -760,6 +760,9 @@ template <typename T> struct SlotLds {
 // phase, q round trip and tail.
 // Lean single-cycle launches on the straight-line path take the 56-byte KLean instead of the 340-byte KArgs (vfik_kernel.h): the
 // handle's state is one arena whose layout follows from (io type, joints, Bpad).  (The diagnostic stamps build keeps KArgs.)
+#ifndef VFIK_SCALAR_KERNARG
+#define VFIK_SCALAR_KERNARG 1     // 0: every kernel takes its argument block by value, as until round 3 (A/B builds)
+#endif
 #ifdef VFIK_STAMPS
 template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = false; };
 #else
@@ -822,8 +825,11 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     }
     // Fetch the kernel arguments the prologue needs with one batch of scalar loads: left to itself the
     // compiler loads them one by one, each time waiting out a full scalar-load latency.
-    asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots), "s"(a.slots_fast),
-                 "s"(a.tool), "s"(a.mixw), "s"(a.kc));
+    // (Entered through cycle_kernel_s / cycle_kernel_x they arrive preloaded in SGPRs, and the rest of the block is best left where
+    // the compiler first needs it.)
+    if constexpr (!VFIK_SCALAR_KERNARG)
+        asm volatile("" ::"s"(a.B), "s"(a.block), "s"(a.Bpad), "s"(a.slots_used), "s"(a.tool_stride), "s"(a.q), "s"(a.goal), "s"(a.slots), "s"(a.slots_fast),
+                     "s"(a.tool), "s"(a.mixw), "s"(a.kc));
     // PERS: one wave per block; chunk = 64 consecutive arms; lanes past the end of the batch compute arm B - 1 again and store nothing
     const int nchunks = (a.B + 63) >> 6;
     int chunk = PERS ? (int)blockIdx.x : 0;
@@ -1968,6 +1974,32 @@ cycle_kernel_s(const void* base, const void* q, void* qdot_out, int* status, int
     k.B = B; k.Bpad = Bpad; k.slots_used = slots_used; k.fast_order = fast_order; k.flags = flags; k.block = block;
     cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(k);
 }
+// The members of the handle's state arena and the launch's first arguments, from scalars (the arena's layout: vfik_kernel.h)
+template <typename T, int NJ>
+__device__ __forceinline__ void args_from_scalars(KArgs& a, const void* base, const void* q, void* qdot_out, int* status, int B, int Bpad, int slots_used,
+                                                  unsigned flags) {
+    a.q = q; a.qdot_out = qdot_out; a.status = status;
+    a.B = B; a.Bpad = Bpad; a.slots_used = slots_used; a.flags = flags;
+    const char* const b = static_cast<const char*>(base);
+    a.goal = b;
+    a.funnel = b + ArenaLayout<T, NJ>::funnel_off(Bpad);
+    a.kc = b + ArenaLayout<T, NJ>::kconst_off(Bpad);
+    a.lastvec = reinterpret_cast<float*>(const_cast<char*>(b) + ArenaLayout<T, NJ>::lastvec_off(Bpad));
+    a.slots_fast = b + ArenaLayout<T, NJ>::slots_fast_off(Bpad);
+}
+// Every other variant: the same ten scalars IN FRONT of the argument block -- what the prologue needs to issue its first requests (the
+// arena's members, q, the sizes) arrives preloaded; the rest of the block is read by scalar loads that run under those requests.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+cycle_kernel_x(const void* base, const void* q, void* qdot_out, const int* active, int B, int Bpad, int slots_used, int fast_order, unsigned flags, int block,
+               const KArgs a_in) {
+    static_assert(!SmallArgs<LEAN, ROLL, FASTF>::value, "the KLean variants take cycle_kernel_s");
+    KArgs a = a_in;
+    args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
+    a.active = active;   // (the fresh-q gate is the first request of the prologue; status is stored last and stays in the block)
+    a.fast_order = fast_order; a.block = block;
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(a);
+}
 
 
 // CommandMixer.read's weighted sum alone (command_mixer.py:78-82): out = sum_k cmd[k] * w[k], left to
@@ -2156,7 +2188,7 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
 // ------------------------------------------------------------------------------------------------
 #define VFIK_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // one wave per block: in-order LDS queue, no s_barrier needed
 template <typename T, int NJ, bool NS>
-__global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
+__device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
     static_assert(NJ <= 8 && (!NS || NJ <= 7), "one lane per joint; the sign memory is for chains of up to 7 joints");
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, j = lane & 7;
@@ -2472,6 +2504,20 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
     }
 }
 
+// (entry points of the eight-lanes-per-arm kernel: the argument block alone, or the prologue's arguments as preloaded scalars in front)
+template <typename T, int NJ, bool NS>
+__global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
+    cycle_sub8_body<T, NJ, NS>(a);
+}
+template <typename T, int NJ, bool NS>
+__global__ void __launch_bounds__(64)
+cycle_sub8_kernel_x(const void* base, const void* q, void* qdot_out, int* status, const void* slots, int B, int Bpad, int slots_used, unsigned flags, const KArgs a_in) {
+    KArgs a = a_in;
+    args_from_scalars<T, NJ>(a, base, q, qdot_out, status, B, Bpad, slots_used, flags);
+    a.slots = slots;
+    cycle_sub8_body<T, NJ, NS>(a);
+}
+
 // The argument block a kernel variant takes: KLean for the lean single-cycle straight-line variants, KArgs otherwise
 template <int LEAN, bool ROLL, bool FASTF>
 typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type args_for(const KArgs& a) {
@@ -2485,9 +2531,6 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
     }
 }
 
-#ifndef VFIK_SCALAR_KERNARG
-#define VFIK_SCALAR_KERNARG 1
-#endif
 // Launch of a KLean variant (lean, single cycle, straight-line field path): scalar kernel arguments, or the argument block
 template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
 void launch_lean(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
@@ -2496,6 +2539,19 @@ void launch_lean(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                            a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block);
     } else {
         hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES>), grid, blk, lds, stream, args_for<1, false, true>(a));
+    }
+}
+
+// Launch of any other variant: the prologue's arguments as scalars in front of the argument block, or the block alone
+template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false>
+void launch_full(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
+        launch_lean<T, NJ, NS, PL, CF, PERS, FUN>(a, grid, blk, lds, stream);
+    } else if constexpr (VFIK_SCALAR_KERNARG) {
+        hipLaunchKernelGGL((cycle_kernel_x<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out, a.active,
+                           a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block, a);
+    } else {
+        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN>), grid, blk, lds, stream, a);
     }
 }
 
@@ -2532,12 +2588,12 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         if (a.n_cycles > 0) {
             if constexpr (PL) {
                 if (lean) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 1>), grid, blk, lds_lean, stream, a);
+                    launch_full<T, NJ, NS, PL, true, true, 1>(a, grid, blk, lds_lean, stream);
                     return;
                 }
             }
-            if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, true, 0>), grid, blk, lds, stream, a);
-            else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, true, false, 0>), grid, blk, lds, stream, a);
+            if (fastf) launch_full<T, NJ, NS, PL, true, true, 0>(a, grid, blk, lds, stream);
+            else launch_full<T, NJ, NS, PL, true, false, 0>(a, grid, blk, lds, stream);
             return;
         }
     }
@@ -2554,7 +2610,12 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
         if (served && a.B <= cap) {
             const dim3 g8((a.B + 7) / 8), b8(64);
-            hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
+            // (with the nullspace module the scalar entry came out 5 % SLOWER: 68 B of scratch reserved, 6.09 against 5.74 us for one arm)
+            if constexpr (VFIK_SCALAR_KERNARG && !NS)
+                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.status, a.slots, a.B, a.Bpad,
+                                   a.slots_used, a.flags, a);
+            else
+                hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
             if (sub8) *sub8 = 1;
             return;
         }
@@ -2611,7 +2672,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         }
         if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
             if (lean) {
-                hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 2>), grid, blk, lds_lean, stream, a);
+                launch_full<T, NJ, NS, PL, false, true, 2>(a, grid, blk, lds_lean, stream);
                 return;
             }
         }
@@ -2621,22 +2682,22 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
                            !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
         if (lean3 && fun) {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, -1, false, true>), grid, blk, lds_fun, stream, a);
+            launch_full<T, NJ, NS, PL, false, true, 3, -1, false, true>(a, grid, blk, lds_fun, stream);
             return;
         }
         if (lean3) {
             if constexpr (NS && NJ <= 7) {
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, NSMIX>), grid, blk, lds_lean, stream, a);
+                    launch_full<T, NJ, NS, PL, false, true, 3, NSMIX>(a, grid, blk, lds_lean, stream);
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3, NSJLMIX>), grid, blk, lds_lean, stream, a);
+                    launch_full<T, NJ, NS, PL, false, true, 3, NSJLMIX>(a, grid, blk, lds_lean, stream);
                     return;
                 }
             }
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 3>), grid, blk, lds_lean, stream, a);
+            launch_full<T, NJ, NS, PL, false, true, 3>(a, grid, blk, lds_lean, stream);
             return;
         }
     }
@@ -2645,12 +2706,12 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         // object_feeder:248-303) with nothing but q -> qdot_out asked for: its own LEAN variant (the optional inputs and
         // outputs as compile-time nulls free the registers the 14-joint kernel otherwise spills)
         if (lean_any && !fastf && !a.q_out) {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, 1>), grid, blk, lds, stream, a);
+            launch_full<T, NJ, NS, PL, false, false, 1>(a, grid, blk, lds, stream);
             return;
         }
     }
-    if (fastf) hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 0>), grid, blk, lds, stream, a);
-    else hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, false, 0>), grid, blk, lds, stream, a);
+    if (fastf) launch_full<T, NJ, NS, PL, false, true, 0>(a, grid, blk, lds, stream);
+    else launch_full<T, NJ, NS, PL, false, false, 0>(a, grid, blk, lds, stream);
 }
 
 template <typename T, int NJ>
