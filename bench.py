@@ -313,6 +313,15 @@ def worker(args):
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc pass of this command, round %s; not measured by this run)" % rec.get("round")
         except Exception:
             traffic = None
+    # what rocprofv3 measured for this workload's kernel (profiles/kernel_trace.json, written by tools/profile_digest.py from the round's
+    # --kernel-trace --stats runs of this command): quoted beside the live HIP-event figure, never in place of it
+    ktrace = None
+    kt = os.path.join(ROOT, "profiles", "kernel_trace.json")
+    if os.path.exists(kt):
+        try:
+            ktrace = json.load(open(kt)).get(args.workload)
+        except Exception:
+            ktrace = None
     # rotating input sets (the COLD state): enough of them that the bytes touched between two uses of a set exceed 640 MiB
     per_launch = float(traffic) if traffic else float(bytes_per_cycle * B)
     n_sets = 0
@@ -569,6 +578,14 @@ def worker(args):
             line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"
         if cold is not None:
             line["roofline"]["cold"] = cold
+        if ktrace:
+            # under the tracer every dispatch carries profiling work (start/end timestamps, its own completion signal) and the
+            # launches arrive 8-11 us apart: the traced kernel durations are 0.2-0.5 us longer than the untraced launch period above
+            line["roofline"]["kernel_trace"] = {
+                "source": "profiles/kernel_trace.json <- profiles/r%02d_kernel_stats_{warm,cold}_%s.csv (rocprofv3 --kernel-trace --stats of this command; "
+                          "not measured by this run)" % (ktrace.get("round", 0), args.workload),
+                "kernel": ktrace.get("kernel"),
+                **{st: {k: ktrace[st].get(k) for k in ("mean_ns", "median_ns", "min_ns", "dispatches", "frac", "graph_replay")} for st in ("warm", "cold") if st in ktrace}}
         if extra_outs:
             line["config"]["outputs"] = ["qdot_out"] + list(extra_outs)
         if per_rank_ms is not None:

@@ -38,6 +38,7 @@ def main():
     d, rnd = sys.argv[1], int(sys.argv[2])
     print("| workload | state | kernel | dispatches | rocprofv3 mean ns | median | min | frac from the CSV mean | the traced process's own HIP events, us | plain run (no tracer): us per launch, frac |")
     print("|---|---|---|---|---|---|---|---|---|---|")
+    ktrace = {}
     for w in ("C2", "C2F", "C3", "C3N", "C5", "C3F", "C5F"):
         plain = line_of(os.path.join(d, "bench_%s.json" % w))
         for state, tdir, under in (("warm", "trace_", "bench_under_rocprof_%s.json"), ("cold", "cold_trace_", "bench_cold_under_rocprof_%s.json")):
@@ -57,9 +58,24 @@ def main():
                 ptxt = "%.3f, %.3f" % (pus, pr["frac"]) if pus else "-"
             else:
                 ptxt = "-"
+            ktrace.setdefault(w, {"kernel": kernel_of(row["Name"]), "round": rnd, "algorithmic_bytes_per_launch": ALG[w]})[state] = {
+                "mean_ns": mean, "median_ns": statistics.median(dur), "min_ns": int(row["MinNs"]), "dispatches": int(row["Calls"]), "frac": frac_csv,
+                "traced_process_us_per_launch": line["roofline"]["us_per_launch_hip_events"] if line else None}
+            # the same state traced with graph-replayed launches (back to back under the tracer), where the round kept one
+            gst = one(os.path.join(d, "graph_trace_%s_%s" % (state, w), "*", "*kernel_stats.csv"))
+            if gst:
+                shutil.copy(gst, os.path.join(ROOT, "profiles", "r%02d_kernel_stats_graph_%s_%s.csv" % (rnd, state, w)))
+                grow = [r for r in csv.DictReader(open(gst)) if "::cycle_" in r["Name"]][0]
+                gline = line_of(os.path.join(d, "bench_graph_under_rocprof_%s_%s.json" % (state, w)))
+                ktrace[w][state]["graph_replay"] = {"mean_ns": float(grow["AverageNs"]), "min_ns": int(grow["MinNs"]), "dispatches": int(grow["Calls"]),
+                                                    "frac": ALG[w] / (float(grow["AverageNs"]) * 1e-9) / 1e9 / 8000.0,
+                                                    "traced_process_us_per_launch": gline["roofline"]["us_per_launch_hip_events"] if gline else None}
             print("| %s | %s | `%s` | %s | %.0f | %.0f | %s | **%.3f** | %s | %s |" % (
                 w, state, kernel_of(row["Name"]), row["Calls"], mean, statistics.median(dur), row["MinNs"], frac_csv,
                 "%.3f" % line["roofline"]["us_per_launch_hip_events"] if line else "-", ptxt))
+    if ktrace:
+        with open(os.path.join(ROOT, "profiles", "kernel_trace.json"), "w") as f:
+            json.dump(ktrace, f, indent=1)
     traffic = {}
     print()
     for w in ("C3", "C3N", "C5", "C3F", "C5F"):

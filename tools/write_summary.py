@@ -14,7 +14,7 @@ table, traffic, sq = parts[0], parts[1], parts[2]
 R = "r%02d" % rnd
 txt = """# %(R)s -- rocprofv3 summaries of the final round-%(rnd)d build (un-instrumented product library, MI355X, gpurun boxes)
 
-Produced by `tools/profile_round.sh %(tag)s <workloads>` (two calls: C3 C3N C5, then C3F C5F C2; each command with `python3` directly after
+Produced by `tools/profile_round.sh %(tag)s <workloads>` (two calls: C3 C3N C5, then C3F C5F C2 C2F; each command with `python3` directly after
 `--`), digested by `tools/profile_digest.py gpurun_out/%(tag)s %(rnd)d` and laid out by `tools/write_summary.py`.  Raw statistics:
 `%(R)s_kernel_stats_{warm,cold}_<W>.csv`; the bench lines: `%(R)s_bench_<W>.json` (plain runs: warm headline + `roofline.cold`),
 `%(R)s_bench_under_rocprofv3_{warm,cold}_<W>.json` (what the traced commands printed), `%(R)s_bench_driver_command_steps20.json` (the driver's
@@ -36,11 +36,20 @@ C3 / C3N 384 B x 65 536, C5 696 B x 65 536, C3F 600 B x 65 536, C5F 996 B x 65 5
 
 %(table)s
 
-Template parameters of `cycle_kernel`: <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN (1 lean, 3
-publishing lean), compile-time flags, persistent>; of `cycle_sub8_kernel`: <io type, joints, nullspace module>.
+Kernel names: `cycle_kernel_s` = a lean variant entered through its ten scalar arguments (preloaded into SGPRs), `cycle_kernel_x` = any
+other variant (the same scalars in front of its argument block); template parameters <io type, joints, nullspace module, PLAIN, rollout,
+straight-line field path, LEAN (1 lean, 3 publishing lean), compile-time flags, persistent, aux block, waves per SIMD>; of
+`cycle_sub8_kernel[_x]`: <io type, joints, nullspace module>.
 
-The figure to quote is the CSV's (isolated launches: under the tracer the process launches only every 8-11 us).  The plain run's
-launch period (HIP events around 200 back-to-back launches, last column) agrees within a few per cent.
+**Traced against untraced.**  Under the tracer every dispatch carries profiling work (its own completion signal with start / end
+timestamps) and, launched one by one, the dispatches arrive only every 8-11 us (column "the traced process's own HIP events"): each kernel
+then starts on an idle chip.  Until this round the untraced launch period (last column) and the traced mean agreed within 1-4 %%; since the
+kernels take their arguments preloaded (`r03_ab_experiments.md` 14) the untraced period of C3 is 4.88 us while the traced mean stayed at
+5.38 -- the dispatch-side work the preload removed from the wave's prologue is still inside the tracer's start-to-end interval, and
+back-to-back it overlaps the previous kernel's tail.  Traced with the launches replayed from a hipGraph (`--launch graph`: back to back
+under the tracer too; `%(R)s_kernel_stats_graph_{warm,cold}_<W>.csv`, `profiles/kernel_trace.json: graph_replay`) the means are C3 5 115 /
+6 171 ns (0.615 / 0.510), C3N 6 846 / 8 220, C5 10 461 / 11 606, with the traced process's own period 5.36 us.  `bench.py` prints the
+untraced HIP-event figure as `roofline.frac` (what the contract defines) and the traced means beside it (`roofline.kernel_trace`).
 Round 2 (warm only): C3 5 674 ns (0.554), C3N 7 565 (0.416), C5 10 826 (0.527), C2 5 153 (0.051).
 
 ## HBM traffic in the cold state: one counter per pass, `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` / `--pmc WRITE_SIZE ...` (`--state cold --steps 40 --reps 2`; median over the dispatches)
@@ -57,7 +66,7 @@ same figures as round 2's warm passes: FETCH_SIZE counts Infinity-Cache hits too
 %(sq)s
 
 (Units: quad-cycles; instruction counts are exact, wait cycles are inflated by the profiler.)  Round 2: C3 VALU 1 268 / active 1 608,
-C3N 2 013 / 2 457, C5 3 457 / 4 049.  C2's kernel is the eight-lanes-per-arm one.
+C3N 2 013 / 2 457, C5 3 457 / 4 049.  C2's and C2F's kernels are the eight-lanes-per-arm ones: 944 / 1 810 VALU instructions per wave of 8 arms.
 
 ## Other artefacts of the round
 
@@ -66,7 +75,8 @@ C3N 2 013 / 2 457, C5 3 457 / 4 049.  C2's kernel is the eight-lanes-per-arm one
   the parent spawned both ranks (each pinned to its own CPUs), two ranks SHARING one GPU, `ShardedEngine.gather` collated 131 072 rows.
   (8-GPU scaling is the driver's to measure.)
 * Small batches: `%(R)s_latency_small_f64_4obst.txt`, `%(R)s_latency_small_f32_8obst.txt`; floor: `%(R)s_ubench_launch.txt` (+ `_host_kernarg`);
-  cross-lane prices: `%(R)s_ubench_xlane.txt`.  Beyond one wave per SIMD: `%(R)s_batch_scaling.txt`, `%(R)s_stamps_131072_arms_in_rounds.txt`.
+  cross-lane prices: `%(R)s_ubench_xlane.txt`.  Beyond one wave per SIMD: `%(R)s_batch_scaling.txt` (rounds / two waves per SIMD / persistent),
+  `%(R)s_stamps_131072_arms_in_rounds.txt`.  Field paths: `%(R)s_general_path.txt`.
 * Drop-in path: `%(R)s_ccb_rate.txt` (ControlCycleBatch.cycle() with ports / step_arrays with every output / qdot_out only).
 * Stamps (diagnostic build): `%(R)s_stamps_C3_{warm,cold}.txt`, `%(R)s_stamps_C3N_{warm,cold}.txt`, `%(R)s_stamps_C3F_warm.txt`.
 * A/B log: `%(R)s_ab_experiments.md` with its raw files.
