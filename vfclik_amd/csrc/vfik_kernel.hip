@@ -760,6 +760,9 @@ template <typename T> struct SlotLds {
 // phase, q round trip and tail.
 // Lean single-cycle launches on the straight-line path take the 56-byte KLean instead of the 340-byte KArgs (vfik_kernel.h): the
 // handle's state is one arena whose layout follows from (io type, joints, Bpad).  (The diagnostic stamps build keeps KArgs.)
+#ifndef VFIK_NT_STORES
+#define VFIK_NT_STORES 0          // 1: the lane-by-lane output stores non-temporal (A/B builds)
+#endif
 #ifndef VFIK_SCALAR_KERNARG
 #define VFIK_SCALAR_KERNARG 1     // 0: every kernel takes its argument block by value, as until round 3 (A/B builds)
 #endif
@@ -1853,7 +1856,13 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
                 asm volatile("" ::: "memory");
             } else {
     #pragma unroll
-                for (int i = 0; i < K; ++i) o[(long)arm * K + i] = (T)val(i);
+                for (int i = 0; i < K; ++i) {
+#if VFIK_NT_STORES
+                    __builtin_nontemporal_store((T)val(i), &o[(long)arm * K + i]);
+#else
+                    o[(long)arm * K + i] = (T)val(i);
+#endif
+                }
             }
         };
         typedef std::integral_constant<int, NJ> KNJ;
