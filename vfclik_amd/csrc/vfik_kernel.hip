@@ -951,6 +951,11 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
+    // The members of the argument block the rest of the cycle needs, in one batch of scalar loads behind the requests (cycle_kernel_x:
+    // left alone, the compiler fetches each where it is first used -- a round trip to the kernarg segment every time)
+    if constexpr (VFIK_SCALAR_KERNARG && !SmallArgs<LEAN, ROLL, FASTF>::value)
+        asm volatile("" ::"s"(a.null_control), "s"(a.qdot_vf), "s"(a.qdot_null), "s"(a.pose), "s"(a.pose_nt), "s"(a.v6), "s"(a.qdist), "s"(a.goal_dist),
+                     "s"(a.status), "s"(a.q_out), "s"(a.ext), "s"(a.q_ref), "s"(a.q_cmded), "s"(a.q_lo), "s"(a.q_hi), "s"(a.q_ref_out), "s"(a.wts));
     STAMP(1);
     // ---------------- A3: forward kinematics (vf:316-318) -------------------------------------
     double q[NJ], sn[NJ], cs[NJ];
@@ -2257,6 +2262,11 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
         has_vec = fabsf(sv[NJ]) > 1.5f;
         if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
     }
+    // The members of the argument block the rest of the kernel needs, in ONE batch of scalar loads behind the requests above (entered
+    // through cycle_sub8_kernel_x, whose scalars are preloaded, the compiler otherwise fetches them one by one where each is first
+    // used, every time a full round trip to the kernarg segment).
+    if constexpr (VFIK_SCALAR_KERNARG)
+        asm volatile("" ::"s"(a.qdot_vf), "s"(a.qdot_null), "s"(a.pose), "s"(a.pose_nt), "s"(a.qdist), "s"(a.status));
 
     // ---- A3: sin / cos of joint j on lane j, exchanged through LDS
     {
@@ -2520,10 +2530,12 @@ __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
 }
 template <typename T, int NJ, bool NS>
 __global__ void __launch_bounds__(64)
-cycle_sub8_kernel_x(const void* base, const void* q, void* qdot_out, int* status, const void* slots, int B, int Bpad, int slots_used, unsigned flags, const KArgs a_in) {
+cycle_sub8_kernel_x(const void* base, const void* q, void* qdot_out, const void* null_control, const void* slots, int B, int Bpad, int slots_used, unsigned flags,
+                    const KArgs a_in) {
     KArgs a = a_in;
-    args_from_scalars<T, NJ>(a, base, q, qdot_out, status, B, Bpad, slots_used, flags);
+    args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
     a.slots = slots;
+    a.null_control = null_control;   // (read up front; status is stored last and stays in the block)
     cycle_sub8_body<T, NJ, NS>(a);
 }
 
@@ -2619,9 +2631,10 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
         if (served && a.B <= cap) {
             const dim3 g8((a.B + 7) / 8), b8(64);
-            // (with the nullspace module the scalar entry came out 5 % SLOWER: 68 B of scratch reserved, 6.09 against 5.74 us for one arm)
+            // (with the nullspace module the scalar entry measures 1-2 % SLOWER -- one arm 5.83 against 5.73 us, C2F 7.17 against 7.07 --
+            // with or without a batch fetch of the block's other members: that variant keeps the block entry)
             if constexpr (VFIK_SCALAR_KERNARG && !NS)
-                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.status, a.slots, a.B, a.Bpad,
+                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
                                    a.slots_used, a.flags, a);
             else
                 hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
