@@ -579,13 +579,13 @@ def worker(args):
         if cold is not None:
             line["roofline"]["cold"] = cold
         if ktrace:
-            # under the tracer every dispatch carries profiling work (start/end timestamps, its own completion signal) and the
-            # launches arrive 8-11 us apart: the traced kernel durations are 0.2-0.5 us longer than the untraced launch period above
+            # (traced with the launches replayed from a hipGraph, back to back as in the untraced run; under the tracer every dispatch
+            # carries profiling work: the traced means run 1-5 % above the untraced launch period)
             line["roofline"]["kernel_trace"] = {
-                "source": "profiles/kernel_trace.json <- profiles/r%02d_kernel_stats_{warm,cold}_%s.csv (rocprofv3 --kernel-trace --stats of this command; "
-                          "not measured by this run)" % (ktrace.get("round", 0), args.workload),
+                "source": "profiles/kernel_trace.json <- profiles/r%02d_kernel_stats_{warm,cold}_%s.csv (rocprofv3 --kernel-trace --stats of this command "
+                          "with --launch graph; not measured by this run)" % (ktrace.get("round", 0), args.workload),
                 "kernel": ktrace.get("kernel"),
-                **{st: {k: ktrace[st].get(k) for k in ("mean_ns", "median_ns", "min_ns", "dispatches", "frac", "graph_replay")} for st in ("warm", "cold") if st in ktrace}}
+                **{st: {k: ktrace[st].get(k) for k in ("mean_ns", "median_ns", "min_ns", "dispatches", "frac")} for st in ("warm", "cold") if st in ktrace}}
         if extra_outs:
             line["config"]["outputs"] = ["qdot_out"] + list(extra_outs)
         if per_rank_ms is not None:

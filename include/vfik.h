@@ -272,6 +272,10 @@ int vfik_slots_in_use(vfik_handle* h);
  * repeller + obstacles) and a surface (ObstacleH, object_feeder:344-353);
  * 0 = general: anything else (further attractors, several funnels or hemispheres, fractional or mixed orders), entry by entry. */
 int vfik_field_path(vfik_handle* h);
+/* 1 when every decay repeller of the batch carries the same safe distance and the same force -- what the object feeder sends
+ * (0.001 and -10 for every point obstacle and for the near-goal repeller: object_feeder:301-302,323,331): on field path 1 the lean
+ * launches then read one quad (x y z radius) per repeller instead of 24 bytes, the pair from the batch constants.  0 otherwise. */
+int vfik_uniform_repellers(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);
 
 #ifdef __cplusplus

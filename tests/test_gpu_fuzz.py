@@ -22,6 +22,9 @@ def env():
 
 def _random_fields(abi, chain, B, rng, dt, general):
     M = int(rng.integers(1, 9))
+    # half of the configurations: one (safe distance, force) for every decay repeller, as the object feeder sends them -- the
+    # uniform repeller image; the others mix two of each -- the compact image
+    mixed = bool(rng.integers(0, 2))
     F = np.zeros((B, M), dtype=abi.FIELD_DTYPE)
     n = np.zeros(B, dtype=np.int32)
     order = float(rng.choice([2.0, 5.0, 20.0]))
@@ -37,8 +40,9 @@ def _random_fields(abi, chain, B, rng, dt, general):
                 f["p"][:16] = chain.fk(rng.uniform(0.8 * chain.q_lo, 0.8 * chain.q_hi))[0].reshape(16)
                 f["p"][16] = rng.uniform(0.02, 0.2)
             elif t == 2:
-                f["force"] = -10.0
-                f["p"][:6] = [*rng.uniform(-0.8, 0.8, 2), rng.uniform(0, 1.2), rng.uniform(0.03, 0.1), 0.001,
+                f["force"] = float(rng.choice([-10.0, -4.0])) if mixed else -10.0
+                f["p"][:6] = [*rng.uniform(-0.8, 0.8, 2), rng.uniform(0, 1.2), rng.uniform(0.03, 0.1),
+                              float(rng.choice([0.001, 0.004])) if mixed else 0.001,
                               order if not general else float(rng.choice([2.0, 5.0, 3.5]))]
             elif t == 4:
                 f["force"] = -50.0

@@ -763,6 +763,71 @@ def test_goal_and_normal_scene_on_the_straight_line_path(env, robot, B, dt, tol,
     eng.close()
 
 
+@pytest.mark.parametrize("robot,B,dt,tol,flags,nobs,want", [
+    ("lwr", 65536, np.float32, TOL32, 0, 8, ("qdot_out", "status")),      # C3, lean
+    ("lwr", 20000, np.float32, TOL32, 5, 8, None),                        # default process set, every row (publishing lean)
+    ("lwr_dual14", 9000, np.float32, TOL32, 7, 16, ("qdot_out", "status")),   # C5's shape: two chunks of slots
+    ("lwr", 3000, np.float64, TOL64, 7, 11, None),                        # float64 I/O: chunks of 4
+    ("powercube6", 1000, np.float32, TOL32, 0, 3, ("qdot_out", "status")),
+])
+def test_uniform_repeller_image(env, monkeypatch, robot, B, dt, tol, flags, nobs, want):
+    """Every decay repeller of the batch with the object feeder's safe distance and force (object_feeder:301-302,323,331): the lean
+    launches read the uniform image (one quad per repeller, the pair in the batch constants).  Against the oracle; against the
+    compact image (VFIK_UNIFORM_IMAGE=0); and a batch in which ONE arm's repeller differs falls back to the compact image."""
+    chain = env.robots.by_name(robot)
+    want = want or ALL
+    w = env.synth.make_workload(chain, B, nobs, seed=31, io_dtype=dt)
+    # ragged: a third of the arms with fewer obstacles (down to the goal alone, or nothing at all)
+    rng = np.random.default_rng(B)
+    few = rng.random(B) < 0.33
+    w["nfields"][few] = rng.integers(0, nobs + 1, int(few.sum()))
+    params = env.abi.default_params(flags=flags)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"])
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=nobs, params=params)
+    eng.set_small_batch_kernel(0)
+    # (first a sub-range only: the arms not yet given a field set must read as empty in the uniform image too)
+    eng.set_fields(w["fields"][:B // 2], w["nfields"][:B // 2])
+    nf_half = w["nfields"].copy()
+    nf_half[B // 2:] = 0
+    ref_half = env.oc.cycle_batch(chain, params, w["q"], w["fields"], nf_half, want=("qdot_out", "status"))
+    _compare(eng.step_host(w["q"], want=("qdot_out", "status")), ref_half, tol, ("qdot_out", "status"))
+    eng.reset_state()
+    eng.set_fields(w["fields"], w["nfields"])
+    assert eng.field_path == 1 and eng.uniform_repellers
+    got = eng.step_host(w["q"], want=want)
+    _compare(got, ref, tol, want)
+    monkeypatch.setenv("VFIK_UNIFORM_IMAGE", "0")
+    eng0 = env.engine.Engine(chain, B, io_dtype=dt, max_slots=nobs, params=params)
+    monkeypatch.delenv("VFIK_UNIFORM_IMAGE")
+    eng0.set_small_batch_kernel(0)
+    eng0.set_fields(w["fields"], w["nfields"])
+    assert eng0.field_path == 1 and not eng0.uniform_repellers
+    got0 = eng0.step_host(w["q"], want=want)
+    _compare(got0, ref, tol, want)
+    eng0.close()
+    # one arm's third repeller with another safe distance: the compact image for everybody, same results but for that arm
+    F2 = w["fields"].copy()
+    odd = int(np.nonzero(w["nfields"] == nobs + 1)[0][B // 200])
+    F2["p"][odd, min(3, nobs), 4] = np.float64(dt(0.004))
+    eng.set_fields(F2[odd:odd + 1], w["nfields"][odd:odd + 1], first_arm=odd)
+    assert eng.field_path == 1 and not eng.uniform_repellers
+    ref2 = env.oc.cycle_batch(chain, params, w["q"], F2, w["nfields"])
+    eng.reset_state()
+    _compare(eng.step_host(w["q"], want=want), ref2, tol, want)
+    # ... and back; then a batch-wide change of the pair (another force for every repeller): the constants follow
+    eng.set_fields(w["fields"][odd:odd + 1], w["nfields"][odd:odd + 1], first_arm=odd)
+    assert eng.uniform_repellers
+    F3 = w["fields"].copy()
+    F3["force"][:, 1:1 + nobs] = -6.0
+    F3["p"][:, 1:1 + nobs, 4] = np.float64(dt(0.002))
+    eng.set_fields(F3, w["nfields"])
+    assert eng.uniform_repellers
+    ref3 = env.oc.cycle_batch(chain, params, w["q"], F3, w["nfields"])
+    eng.reset_state()
+    _compare(eng.step_host(w["q"], want=want), ref3, tol, want)
+    eng.close()
+
+
 def test_field_path_classification(env):
     chain = env.robots.lwr()
     f = env.abi

@@ -61,15 +61,15 @@ def main():
             ktrace.setdefault(w, {"kernel": kernel_of(row["Name"]), "round": rnd, "algorithmic_bytes_per_launch": ALG[w]})[state] = {
                 "mean_ns": mean, "median_ns": statistics.median(dur), "min_ns": int(row["MinNs"]), "dispatches": int(row["Calls"]), "frac": frac_csv,
                 "traced_process_us_per_launch": line["roofline"]["us_per_launch_hip_events"] if line else None}
-            # the same state traced with graph-replayed launches (back to back under the tracer), where the round kept one
-            gst = one(os.path.join(d, "graph_trace_%s_%s" % (state, w), "*", "*kernel_stats.csv"))
-            if gst:
-                shutil.copy(gst, os.path.join(ROOT, "profiles", "r%02d_kernel_stats_graph_%s_%s.csv" % (rnd, state, w)))
-                grow = [r for r in csv.DictReader(open(gst)) if "::cycle_" in r["Name"]][0]
-                gline = line_of(os.path.join(d, "bench_graph_under_rocprof_%s_%s.json" % (state, w)))
-                ktrace[w][state]["graph_replay"] = {"mean_ns": float(grow["AverageNs"]), "min_ns": int(grow["MinNs"]), "dispatches": int(grow["Calls"]),
-                                                    "frac": ALG[w] / (float(grow["AverageNs"]) * 1e-9) / 1e9 / 8000.0,
-                                                    "traced_process_us_per_launch": gline["roofline"]["us_per_launch_hip_events"] if gline else None}
+            # the same command launched one by one under the tracer (host-bound there: durations include queueing), kept for the record
+            dst = one(os.path.join(d, ("direct_trace_" if state == "warm" else "direct_cold_trace_") + w, "*", "*kernel_stats.csv"))
+            if dst:
+                shutil.copy(dst, os.path.join(ROOT, "profiles", "r%02d_kernel_stats_direct_%s_%s.csv" % (rnd, state, w)))
+                drow = [r for r in csv.DictReader(open(dst)) if "::cycle_" in r["Name"]][0]
+                dline = line_of(os.path.join(d, ("bench_direct_under_rocprof_%s.json" if state == "warm" else "bench_direct_cold_under_rocprof_%s.json") % w))
+                ktrace[w][state]["launched_one_by_one_under_the_tracer"] = {
+                    "mean_ns": float(drow["AverageNs"]), "min_ns": int(drow["MinNs"]), "dispatches": int(drow["Calls"]),
+                    "traced_process_us_per_launch": dline["roofline"]["us_per_launch_hip_events"] if dline else None}
             print("| %s | %s | `%s` | %s | %.0f | %.0f | %s | **%.3f** | %s | %s |" % (
                 w, state, kernel_of(row["Name"]), row["Calls"], mean, statistics.median(dur), row["MinNs"], frac_csv,
                 "%.3f" % line["roofline"]["us_per_launch_hip_events"] if line else "-", ptxt))

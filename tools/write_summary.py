@@ -29,7 +29,7 @@ command), `%(R)s_bench_n2_gloo_single_device.json`.
   buffers; >= 640 MiB touched between two uses of a set): inputs come from HBM.  The plain `bench.py` line carries both
   (`roofline.state`, `roofline.cold`).
 
-## Kernel trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload W --no-cpu-baseline --rollout 0 --host-path 0 --state {warm,cold}`
+## Kernel trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload W --no-cpu-baseline --rollout 0 --host-path 0 --launch graph --state {warm,cold}`
 
 (12 020+ dispatches each: warm-up + 2 x 30 repetitions x 200 launches.  Algorithmic bytes per launch, SURVEY 8d: C2 512 B x 4 096,
 C3 / C3N 384 B x 65 536, C5 696 B x 65 536, C3F 600 B x 65 536, C5F 996 B x 65 536.  frac = algorithmic bytes / mean duration / 8 TB/s.)
@@ -41,16 +41,17 @@ other variant (the same scalars in front of its argument block); template parame
 straight-line field path, LEAN (1 lean, 3 publishing lean), compile-time flags, persistent, aux block, waves per SIMD>; of
 `cycle_sub8_kernel[_x]`: <io type, joints, nullspace module>.
 
-**Traced against untraced.**  Under the tracer every dispatch carries profiling work (its own completion signal with start / end
-timestamps) and, launched one by one, the dispatches arrive only every 8-11 us (column "the traced process's own HIP events"): each kernel
-then starts on an idle chip.  Until this round the untraced launch period (last column) and the traced mean agreed within 1-4 %%; since the
-kernels take their arguments preloaded (`r03_ab_experiments.md` 14) the untraced period of C3 is 4.88 us while the traced mean stayed at
-5.38 -- the dispatch-side work the preload removed from the wave's prologue is still inside the tracer's start-to-end interval, and
-back-to-back it overlaps the previous kernel's tail.  Traced with the launches replayed from a hipGraph (`--launch graph`: back to back
-under the tracer too; `%(R)s_kernel_stats_graph_{warm,cold}_<W>.csv`, `profiles/kernel_trace.json: graph_replay`) the means are C3 5 115 /
-6 171 ns (0.615 / 0.510), C3N 6 846 / 8 220, C5 10 461 / 11 606, with the traced process's own period 5.36 us.  `bench.py` prints the
-untraced HIP-event figure as `roofline.frac` (what the contract defines) and the traced means beside it (`roofline.kernel_trace`).
-Round 2 (warm only): C3 5 674 ns (0.554), C3N 7 565 (0.416), C5 10 826 (0.527), C2 5 153 (0.051).
+**How the traces were taken, and traced against untraced.**  The traced commands replay their launches from a hipGraph (`--launch graph`,
+what the plain command's `auto` mode picks at 200 launches per region): back to back under the tracer as in the untraced run, start-to-start
+= duration (`%(R)s_trace_gaps.txt`).  Launched one by one, the tracer's per-dispatch work makes the process host-bound (8-11 us per launch for
+the short kernels: column "the traced process's own HIP events" of the `direct` traces), and the recorded durations turn bimodal and inflated --
+C3: 6 216 ns mean (median 6 160, p10 4 640, p90 7 720) against 5 164 (5 040 / 4 960 / 5 280) graph-replayed on the same box, and a kernel that
+follows an idle gap of more than 3 us runs 0.7-1.6 us longer in every trace (`tools/trace_gaps.py`).  Those one-by-one traces are kept as
+`%(R)s_kernel_stats_direct_{warm,cold}_<W>.csv` for C3, C3N, C5 (for the launches of 10 us and more the two kinds agree: C3F 10 324 / 10 309).
+The traced means run 1-5 %% above the untraced launch period of the last column (every dispatch carries the tracer's completion signal
+and timestamps): `bench.py` prints the untraced HIP-event figure as `roofline.frac`, which is what its contract defines, and the traced
+means beside it (`roofline.kernel_trace`, from `profiles/kernel_trace.json`).
+Round 2 (warm only, launched one by one): C3 5 674 ns (0.554), C3N 7 565 (0.416), C5 10 826 (0.527), C2 5 153 (0.051).
 
 ## HBM traffic in the cold state: one counter per pass, `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` / `--pmc WRITE_SIZE ...` (`--state cold --steps 40 --reps 2`; median over the dispatches)
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/vfik.h"
@@ -78,6 +79,12 @@ struct vfik_handle {
     void* d_goal = nullptr;    // 4 quad planes
     void* d_funnel = nullptr;  // aux block, 6 quad planes: the arm's funnel attractor (3) and hemisphere repeller (3) on the straight-line path (vfik_kernel.h)
     void* d_slots = nullptr;   // 2*S quad planes
+    void* d_slots_uni = nullptr;   // uniform repeller image: ONE quad plane per slot (x y z radius); read when every decay repeller of the batch shares safe distance and force
+    std::vector<char> arm_pair_state;     // per arm: 0 no decay repeller, 1 all of them share one (safe, force), 2 mixed
+    std::vector<double> arm_safe, arm_force;
+    int uni_allowed = 1;                  // VFIK_UNIFORM_IMAGE=0: always the compact image (tests, A/B)
+    int uni_ok = 0;                       // the batch's decay repellers share one pair, now in the device constants (KConst::rep_safe, dh[0].pad)
+    double uni_safe = 0.0, uni_force = 0.0;
     void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
     void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
     double tool_shared[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -166,7 +173,8 @@ void put(std::vector<char>& buf, size_t idx, double v) {
 template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
                  std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used,
-                 std::vector<char>& funnel, std::vector<int>& used_fast, std::vector<char>& has_funnel) {
+                 std::vector<char>& funnel, std::vector<int>& used_fast, std::vector<char>& has_funnel,
+                 std::vector<char>& uni, std::vector<char>& pair_state, std::vector<double>& pair_safe, std::vector<double>& pair_force) {
     funnel.assign((size_t)6 * n_arms * 4 * sizeof(T), 0);  // aux block: funnel planes 0..2, hemisphere planes 3..5
     goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
     slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
@@ -174,6 +182,11 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
     // one number for the batch on the straight-line path and the type is known), so two slots share three quads:
     // (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1).  Slots of another type leave zeros (force 0): they force the general path.
     fast.assign((size_t)3 * ((std::max(1, S) + 1) / 2) * n_arms * 4 * sizeof(T), 0);
+    // uniform image: when every decay repeller of the BATCH has the same safe distance and force (what the object feeder sends:
+    // 0.001 and -10, object_feeder:301-302,323,331) a slot is one quad (x y z radius) and the pair lives in the constants
+    uni.assign((size_t)std::max(1, S) * n_arms * 4 * sizeof(T), 0);
+    // (the force being the batch's, a slot an arm does not use cannot carry force 0 as in the other images: its radius is -inf)
+    for (size_t q4 = 0; q4 < (size_t)std::max(1, S) * n_arms; ++q4) put<T>(uni, q4 * 4 + 3, -std::numeric_limits<double>::infinity());
     std::vector<int> order;
     for (int j = 0; j < n_arms; ++j) {
         const vfik_field* f = fields + (size_t)j * max_fields;
@@ -181,6 +194,7 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
         for (int k = 0; k < counts[j]; ++k) order[k] = k;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f[a].id < f[b].id; });
         bool have_goal = false, have_funnel = false, have_hemi = false;
+        pair_state[j] = 0; pair_safe[j] = 0.0; pair_force[j] = 0.0;
         int m = 0, mr = 0;  // general slots used; compact-image slots used (repellers only, packed densely)
         auto gq = [&](int e) { return ((size_t)(e >> 2) * n_arms + j) * 4 + (e & 3); };
         for (int k : order) {
@@ -212,6 +226,11 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
                 for (int e = 0; e < 12; ++e) put<T>(funnel, ((size_t)(3 + (e >> 2)) * n_arms + j) * 4 + (e & 3), blk[e]);
             }
             if (fd.type == VFIK_FIELD_REPELLER) {
+                for (int e = 0; e < 4; ++e) put<T>(uni, ((size_t)mr * n_arms + j) * 4 + e, fd.p[e]);
+                // (compared as the device will see them: rounded to the I/O type)
+                const double sv = (double)static_cast<T>(fd.p[4]), fv = (double)static_cast<T>(fd.force);
+                if (pair_state[j] == 0) { pair_state[j] = 1; pair_safe[j] = sv; pair_force[j] = fv; }
+                else if (pair_safe[j] != sv || pair_force[j] != fv) pair_state[j] = 2;
                 const int pair = mr >> 1, half = mr & 1;
                 ++mr;
                 for (int i = 0; i < 6; ++i) {
@@ -278,6 +297,8 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.has_funnel = h->any_funnel;
     a.pers = h->pers;
     a.waves2 = h->waves2;
+    a.uni = h->uni_ok && h->uni_allowed;
+    a.uni_planes = 3 * ((std::max(1, h->max_slots) + 1) / 2);
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
 }
@@ -289,6 +310,8 @@ int upload_kconst(vfik_handle* h) {
     int plain = 0;
     const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared, &plain);
     if (!(err < 1e-9)) return fail(VFIK_E_ARG, "chain: a fixed transform is not a rigid motion (DH recomposition error %.3e)", err);
+    std::memcpy(img.data() + VFIK_KCONST_REP_SAFE_OFF(h->n), &h->uni_safe, sizeof(double));   // the batch's uniform repeller pair (vfik_set_fields)
+    std::memcpy(img.data() + VFIK_KCONST_REP_FORCE_OFF, &h->uni_force, sizeof(double));
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->d_kconst, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -375,6 +398,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (const char* e = std::getenv("VFIK_SUB8_MAX_BATCH")) h->sub8_max_batch = h->sub8_max_batch_full = h->sub8_max_batch_ns = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_TWO_WAVES")) h->waves2 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VFIK_UNIFORM_IMAGE")) h->uni_allowed = std::atoi(e) != 0;
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
@@ -390,20 +414,36 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         const size_t sz_kc = VFIK_KCONST_SLOT(vfik::kconst_bytes(n_joints));   // (+ slack inside: the kinematics block is copied in whole 1-KiB rows)
         const size_t sz_lv = (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float);
         const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
+        const size_t sz_su = std::max<size_t>(1, (size_t)max_slots) * quad_plane;      // uniform image: one quad plane per slot
         const size_t sz_sl = std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane;  // >= 1 slot: the prefetch reads slot 0
-        if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_sl, true)) return bail("alloc state arena");
+        if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_su + sz_sl, true)) return bail("alloc state arena");
         char* a0 = static_cast<char*>(h->d_arena);
         h->d_goal = a0;
         h->d_funnel = a0 + 4 * quad_plane;
         h->d_kconst = a0 + sz_goal;
         h->d_lastvec = reinterpret_cast<float*>(a0 + sz_goal + sz_kc);
         h->d_slots_fast = a0 + sz_goal + sz_kc + sz_lv;
-        h->d_slots = a0 + sz_goal + sz_kc + sz_lv + sz_sf;
+        h->d_slots_uni = a0 + sz_goal + sz_kc + sz_lv + sz_sf;   // (kernel side: slots_fast + uni_planes quad planes)
+        h->d_slots = a0 + sz_goal + sz_kc + sz_lv + sz_sf + sz_su;
+    }
+    {   // the uniform image starts out with every slot unused (radius -inf), like the zeros (force 0) of the other two images
+        std::vector<char> plane((size_t)h->Bpad * 4 * h->esz, 0);
+        for (int b = 0; b < h->Bpad; ++b) {
+            if (io_dtype == 32) put<float>(plane, (size_t)b * 4 + 3, -std::numeric_limits<double>::infinity());
+            else put<double>(plane, (size_t)b * 4 + 3, -std::numeric_limits<double>::infinity());
+        }
+        for (int sidx = 0; sidx < std::max(1, max_slots); ++sidx)
+            if (hipMemcpyAsync(static_cast<char*>(h->d_slots_uni) + (size_t)sidx * plane.size(), plane.data(), plane.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+                return bail("init uniform image");
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail("init uniform image");
     }
     if (dev_alloc(h, (void**)&h->d_mixw, 16 * sizeof(double), true)) return bail("alloc mixw");
     h->slots_per_arm.assign(B, 0);
     h->fast_slots_per_arm.assign(B, 0);
     h->arm_has_funnel.assign(B, 0);
+    h->arm_pair_state.assign(B, 0);
+    h->arm_safe.assign(B, 0.0);
+    h->arm_force.assign(B, 0.0);
     h->arm_order.assign(B, -1);
 #ifdef VFIK_STAMPS
     if (dev_alloc(h, (void**)&h->d_stamps, ((B + 63) / 64) * 10 * sizeof(unsigned long long), true)) return bail("alloc stamps");
@@ -612,11 +652,12 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         if (need > h->max_slots) return fail(VFIK_E_ARG, "arm %d needs %d slots, handle capacity is %d", first_arm + j, need, h->max_slots);
     }
     HIP_TRY(hipSetDevice(h->device));
-    std::vector<char> goal, slots, fast, funnel, hasf(n_arms);
+    std::vector<char> goal, slots, fast, funnel, hasf(n_arms), uni, pstate(n_arms);
+    std::vector<double> psafe(n_arms), pforce(n_arms);
     std::vector<int> used(n_arms), used_fast(n_arms);
     const int S = h->max_slots;
-    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf);
-    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf);
+    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce);
+    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce);
     const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
     char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
@@ -628,6 +669,8 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
         char* df = static_cast<char*>(h->d_slots_fast) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(df, pitch, fast.data(), w, w, (size_t)((S + 1) / 2) * 3, hipMemcpyHostToDevice, h->stream));
+        char* du = static_cast<char*>(h->d_slots_uni) + (size_t)first_arm * qb;
+        HIP_TRY(hipMemcpy2DAsync(du, pitch, uni.data(), w, w, (size_t)S, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int j = 0; j < n_arms; ++j) {
@@ -635,6 +678,9 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         h->fast_slots_per_arm[first_arm + j] = used_fast[j];
         h->arm_has_funnel[first_arm + j] = hasf[j];
         h->arm_order[first_arm + j] = classify_arm(fields + (size_t)j * max_fields, counts[j]);
+        h->arm_pair_state[first_arm + j] = pstate[j];
+        h->arm_safe[first_arm + j] = psafe[j];
+        h->arm_force[first_arm + j] = pforce[j];
     }
     h->slots_used = *std::max_element(h->slots_per_arm.begin(), h->slots_per_arm.end());
     h->slots_used_fast = *std::max_element(h->fast_slots_per_arm.begin(), h->fast_slots_per_arm.end());
@@ -647,6 +693,27 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         if (o >= 0) fo = o;
     }
     h->fast_order = general ? -1 : (fo < 0 ? 0 : fo);
+    // one (safe distance, force) for every decay repeller of the batch?  Then the pair goes into the device constants and the lean
+    // launches read the uniform image.
+    bool uni_ok = !general, have = false;
+    double us = 0.0, uf = 0.0;
+    for (int b = 0; b < h->B && uni_ok; ++b) {
+        const char st = h->arm_pair_state[b];
+        if (st == 0) continue;
+        if (st == 2) { uni_ok = false; break; }
+        if (!have) { have = true; us = h->arm_safe[b]; uf = h->arm_force[b]; }
+        else if (h->arm_safe[b] != us || h->arm_force[b] != uf) uni_ok = false;
+    }
+    if (uni_ok && have && (us != h->uni_safe || uf != h->uni_force)) {
+        h->uni_safe = us; h->uni_force = uf;
+        if (h->chain_set) {  // (a chain set later writes the pair with the rest of the constants: upload_kconst)
+            char* kc = static_cast<char*>(h->d_kconst);
+            HIP_TRY(hipMemcpyAsync(kc + VFIK_KCONST_REP_SAFE_OFF(h->n), &h->uni_safe, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(kc + VFIK_KCONST_REP_FORCE_OFF, &h->uni_force, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+    }
+    h->uni_ok = uni_ok ? 1 : 0;
     return VFIK_OK;
 }
 
@@ -1238,6 +1305,11 @@ int vfik_field_path(vfik_handle* h) {
     if (!h) return VFIK_E_ARG;
     if (h->fast_order < 0) return 0;
     return h->any_funnel ? 2 : 1;
+}
+
+int vfik_uniform_repellers(vfik_handle* h) {
+    if (!h) return VFIK_E_ARG;
+    return (h->fast_order >= 0 && h->uni_ok && h->uni_allowed) ? 1 : 0;
 }
 
 int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {

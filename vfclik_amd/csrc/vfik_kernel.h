@@ -1,5 +1,6 @@
 // vfik_kernel.h -- kernel argument block shared by vfik_kernel.hip (device) and vfik_abi.cpp (host).
 #pragma once
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,8 +48,11 @@ struct KConst {
     double base[12];  // B[0], row-major 3x4
     // c = crev*cos(q+off) + cprs, s = crev*sin(q+off) + sprs, displacement = qd*q + d: revolute joints have
     // (crev, cprs, sprs, qd) = (1, 0, 0, 0), prismatic ones (0, cos off, sin off, 1) -- arithmetic blends
-    struct DH { double off, crev, cprs, sprs, qd, d, a, ca, sa, pad; } dh[NJ];
-    double tail_c, tail_s, tail_e, tail_pad;  // trailing z-screw of the last fixed transform
+    struct DH { double off, crev, cprs, sprs, qd, d, a, ca, sa, pad; } dh[NJ];   // dh[0].pad: the batch's uniform repeller FORCE (below)
+    double tail_c, tail_s, tail_e;  // trailing z-screw of the last fixed transform
+    // safe distance of every decay repeller of the batch when they all share one (and one force, dh[0].pad): the uniform repeller
+    // image of the straight-line path then carries (x y z radius) per slot only (vfik_abi.cpp: pack_fields, vfik_set_fields)
+    double rep_safe;
     // ---- everything else: read through the scalar cache.  Ordered by use on the lean paths: the first members share the 1-KiB
     // rows that every wave copies to LDS for the kinematics block, so the L2 has them by the time the scalar loads ask -- with
     // one handle after another (inputs from HBM) the first use of lambda2 / rot_slow cost the wave an HBM round trip (round 3).
@@ -72,6 +76,11 @@ struct KConst {
 };
 // The device image of the constants is KConst<NJ> padded to a multiple of 1 KiB, then the 1-KiB sin / cos table
 // ((sin, cos)(k pi/32), k = 0..63) that every wave copies to LDS with the kinematics block.
+// where the host patches the uniform repeller pair into the device image (vfik_abi.cpp: write_uniform_pair)
+#define VFIK_KCONST_REP_FORCE_OFF ((12 + 9) * 8)
+#define VFIK_KCONST_REP_SAFE_OFF(nj) ((12 + 10 * (nj) + 3) * 8)
+static_assert(offsetof(KConst<7>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(7) && offsetof(KConst<14>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(14), "KConst::rep_safe");
+static_assert(offsetof(KConst<7>, dh) + offsetof(KConst<7>::DH, pad) == VFIK_KCONST_REP_FORCE_OFF, "KConst::dh[0].pad");
 template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KConst<NJ>) + 1023) / 1024 * 1024; };
 
 // Chains longer than this have no registers left for loop-carried state: their rollout is a sequence of
@@ -131,12 +140,14 @@ struct KArgs {
     int slots_used_fast;         // slots of the COMPACT repeller image in use (an arm's funnel is not a slot there)
     int has_funnel;              // some arm's field set has a funnel attractor or a hemisphere repeller (straight-line path: the FUN kernel variants)
     const void* arena;           // the handle's state arena [goal | kconst | lastvec | slots_fast | slots] (arena_layout), or NULL
+    int uni;                     // 1: every decay repeller of the batch shares one safe distance and one force (KConst::rep_safe, dh[0].pad): lean launches read the uniform image
+    int uni_planes;              // quad planes of the compact image = offset of the uniform image behind slots_fast
     int waves2;                  // 1: lean straight-line float launches of more than n_simd waves take the two-waves-per-SIMD build (VFIK_TWO_WAVES=0: never)
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
 };
 
 // The per-handle device state a LEAN launch reads lives in ONE allocation with offsets that follow from (io type, joints, Bpad):
-//   [goal: 4 quad planes | aux (funnel 3, hemisphere 3): 6 quad planes | kconst: KCONST_SLOT(nj) bytes | lastvec: (nj + 4) / 4 planes of 16 B | slots_fast ... | slots ...]
+//   [goal: 4 quad planes | aux (funnel 3, hemisphere 3): 6 quad planes | kconst: KCONST_SLOT(nj) bytes | lastvec: (nj + 4) / 4 planes of 16 B | slots_fast ... | slots_uni ... | slots ...]
 // so that such a launch's kernarg is one base pointer + the io pointers (KLean, 56 bytes) instead of the 340-byte KArgs: what a
 // launch costs the HOST grows with its kernarg (tools/ubench_launch: 32-64 B 2.8 us, 336 B 3.9 us on a slow host), and at a
 // 5-us launch period the enqueue loop is never far from being the bottleneck.

@@ -787,12 +787,16 @@ template <typename T, int NJ> struct ArenaLayout {
 // WAVES = 2: the same lean launch compiled for TWO waves per SIMD (at most 256 registers a lane; with float I/O two blocks' lean
 // regions, 2 x 79 KB, fit a CU's LDS), for batches beyond one wave per SIMD: the second wave issues into the first one's dependency
 // stalls -- 131 072 arms 10.3 -> 9.0 us, 524 288 arms 38.3 -> 34.6 us, same box (profiles/r03_batch_scaling.txt).
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES>
+// UNI = the straight-line path reading the UNIFORM repeller image: every decay repeller of the batch has the same safe distance and
+// force (object_feeder sends 0.001 and -10 for every point obstacle and for the near-goal repeller: object_feeder:301-302,323,331), so a
+// slot is ONE quad (x y z radius) and the pair travels in the constants -- 16 instead of 24 bytes and two thirds of the requests.
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES, bool UNI>
 __device__ __forceinline__ void
 cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type& a_in) {
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
     static_assert(WAVES == 1 || (WAVES == 2 && LEAN == 1 && FASTF && PLAIN && !ROLL && !PERS && !FUN && sizeof(T) == 4 && NJ <= 7), "WAVES 2: lean straight-line float launches only");
+    static_assert(!UNI || (FASTF && PLAIN && !ROLL && !PERS && !FUN && (LEAN == 1 || LEAN == 3)), "UNI: the lean single-cycle straight-line variants");
     KArgs a;
     if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
         a = KArgs{};
@@ -807,6 +811,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
         a.slots = a.slots_fast;  // (never read on the straight-line path)
     } else {
         a = a_in;
+    }
+    if constexpr (UNI) {  // the uniform image sits behind the compact one: its offset in quad planes rides in fast_order's upper bits
+        a.slots_fast = static_cast<const char*>(a.slots_fast) + (long)(a.fast_order >> 8) * a.Bpad * (4 * (long)sizeof(T));
+        a.fast_order &= 255;
     }
     if constexpr (CF >= 0) a.flags = (unsigned)CF;
     // LEAN: 1 = lean, 2 = lean with q_out kept (one cycle of a stepped rollout, long chains), 3 = PUBLISHING lean: no per-arm
@@ -910,7 +918,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     // The straight-line path reads the COMPACT repeller image (two slots in three quads, vfik_kernel.h): a chunk of PRE
     // slots is QPC = 3 PRE / 2 quads instead of 2 PRE -- a quarter fewer bytes and requests for what is, at these
     // batches, the longest wait of the wave (the slots' data is the last to arrive).
-    constexpr int QPC = FASTF ? 3 * PRE / 2 : 2 * PRE;       // slot quads per chunk
+    constexpr int QPC = UNI ? PRE : (FASTF ? 3 * PRE / 2 : 2 * PRE);       // slot quads per chunk
     const char* const goal0 = static_cast<const char*>(a.goal);
     const char* const slots0 = static_cast<const char*>(FASTF ? a.slots_fast : a.slots);
     const char* sg = slots0 + (long)arm * QB;  // this arm's quad of slot plane 0
@@ -922,7 +930,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
         // number of outstanding requests is a compile-time constant for the counted waits
         // (Round 3 tried a wave-uniform fast path without the per-quad compare / select when every slot of the window is in use --
         // ~60 fewer scalar instructions a wave: C3 +1.2 % warm, +0.3 % cold, C5 +-0.1 %; scalar work is not what a lone wave waits for.)
-        const bool in = FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre;
+        const bool in = UNI ? idx < npre : (FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre);
         stage_quad<T, NTL>(slots0 + (long)armx * QB + (in ? (long)idx * planeB : 0), dr, Stage<T>::slot_off(idx, NJ));
     };
     auto issue_slot_quad = [&](int idx) { issue_slot_quad_of(idx, arm, dreg); };
@@ -1433,6 +1441,20 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
             auto chunk = [&](int c0) {
                 const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
                 double dx[PRE], dy[PRE], dz[PRE], rs[PRE], fk[PRE];
+                if constexpr (UNI) {  // a slot = one quad (x y z radius | radius = -inf: unused); safe distance and force are the batch's (KConst)
+                    const double usafe = kl->rep_safe, uforce = kl->dh[0].pad;
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) {
+                        double v[4];
+                        read_quad<T>(dreg, Stage<T>::slot_off(m, NJ), lanec, v);
+                        dx[m] = v[0] - pt[0];
+                        dy[m] = v[1] - pt[1];
+                        dz[m] = v[2] - pt[2];
+                        const bool on = m < ncur && v[3] > -1.0e300;   // (radius -inf: a slot this arm does not use)
+                        rs[m] = on ? v[3] + usafe : 0.0;
+                        fk[m] = on ? uforce : 0.0;
+                    }
+                } else
 #pragma unroll
                 for (int k = 0; k < PRE / 2; ++k) {  // a pair of slots = three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1)
                     double v[12];
@@ -1452,8 +1474,8 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the rows have returned
 #pragma unroll
                     for (int idx = 0; idx < QPC; ++idx) {
-                        const int m = c0 + PRE + 2 * (idx / 3);  // first slot of the quad's pair
-                        const char* sm = sg + (m < a.slots_used ? (long)((c0 + PRE) / 2 * 3 + idx) * planeB : 0);
+                        const int m = UNI ? c0 + PRE + idx : c0 + PRE + 2 * (idx / 3);  // (first) slot of the quad
+                        const char* sm = sg + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
                         stage_quad<T, NTL>(sm, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                 }
@@ -1971,22 +1993,22 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 }
 
 // The kernel proper: the body above behind an argument block (KArgs, or KLean for the lean single-cycle straight-line variants) ...
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(a_in);
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(a_in);
 }
 // ... or, for the KLean variants, behind KLean's ten members as SCALAR kernel arguments: those the command processor can preload into
 // the wave's SGPRs at dispatch (-amdgpu-kernarg-preload-count, Makefile; an argument block passed by value is never preloaded), which
 // takes the scalar-load round trip of the kernarg out of every wave's prologue.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 cycle_kernel_s(const void* base, const void* q, void* qdot_out, int* status, int B, int Bpad, int slots_used, int fast_order, unsigned flags, int block) {
     static_assert(SmallArgs<LEAN, ROLL, FASTF>::value, "scalar arguments: the KLean variants");
     KLean k;
     k.base = base; k.q = q; k.qdot_out = qdot_out; k.status = status;
     k.B = B; k.Bpad = Bpad; k.slots_used = slots_used; k.fast_order = fast_order; k.flags = flags; k.block = block;
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(k);
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(k);
 }
 // The members of the handle's state arena and the launch's first arguments, from scalars (the arena's layout: vfik_kernel.h)
 template <typename T, int NJ>
@@ -2003,7 +2025,7 @@ __device__ __forceinline__ void args_from_scalars(KArgs& a, const void* base, co
 }
 // Every other variant: the same ten scalars IN FRONT of the argument block -- what the prologue needs to issue its first requests (the
 // arena's members, q, the sizes) arrives preloaded; the rest of the block is read by scalar loads that run under those requests.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 cycle_kernel_x(const void* base, const void* q, void* qdot_out, const int* active, int B, int Bpad, int slots_used, int fast_order, unsigned flags, int block,
                const KArgs a_in) {
@@ -2012,7 +2034,7 @@ cycle_kernel_x(const void* base, const void* q, void* qdot_out, const int* activ
     args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
     a.active = active;   // (the fresh-q gate is the first request of the prologue; status is stored last and stays in the block)
     a.fast_order = fast_order; a.block = block;
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES>(a);
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(a);
 }
 
 
@@ -2552,27 +2574,35 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
     }
 }
 
-// Launch of a KLean variant (lean, single cycle, straight-line field path): scalar kernel arguments, or the argument block
-template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1>
-void launch_lean(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+// Launch of a KLean variant (lean, single cycle, straight-line field path): scalar kernel arguments, or the argument block.
+// UNI variants read the uniform repeller image, which sits a.uni_planes quad planes behind the compact one: the offset rides in the
+// upper bits of fast_order (KLean's fourteen dwords are all taken).
+template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
+void launch_lean(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+    KArgs a = a_in;
+    if constexpr (UNI) a.fast_order = (a.fast_order & 255) | (a.uni_planes << 8);
     if constexpr (SmallArgs<1, false, true>::value && VFIK_SCALAR_KERNARG) {
-        hipLaunchKernelGGL((cycle_kernel_s<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out, a.status,
-                           a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block);
+        hipLaunchKernelGGL((cycle_kernel_s<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES, UNI>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out,
+                           a.status, a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block);
     } else {
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES>), grid, blk, lds, stream, args_for<1, false, true>(a));
+        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, false, true, 1, CF, PERS, FUN, WAVES, UNI>), grid, blk, lds, stream, args_for<1, false, true>(a));
     }
 }
 
 // Launch of any other variant: the prologue's arguments as scalars in front of the argument block, or the block alone
-template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false>
-void launch_full(const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, bool UNI = false>
+void launch_full(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
     if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
-        launch_lean<T, NJ, NS, PL, CF, PERS, FUN>(a, grid, blk, lds, stream);
-    } else if constexpr (VFIK_SCALAR_KERNARG) {
-        hipLaunchKernelGGL((cycle_kernel_x<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out, a.active,
-                           a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block, a);
+        launch_lean<T, NJ, NS, PL, CF, PERS, FUN, 1, UNI>(a_in, grid, blk, lds, stream);
     } else {
-        hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN>), grid, blk, lds, stream, a);
+        KArgs a = a_in;
+        if constexpr (UNI) a.fast_order = (a.fast_order & 255) | (a.uni_planes << 8);
+        if constexpr (VFIK_SCALAR_KERNARG) {
+            hipLaunchKernelGGL((cycle_kernel_x<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out,
+                               a.active, a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block, a);
+        } else {
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI>), grid, blk, lds, stream, a);
+        }
     }
 }
 
@@ -2594,6 +2624,9 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         else { fastf = false; a.fast_order = -1; }
     }
     if (fastf) a.slots_used = a.slots_used_fast;  // (the straight-line path counts the slots of the compact image)
+    // every decay repeller of the batch with one safe distance and one force (what the object feeder sends): the lean single-cycle
+    // variants read the uniform image -- one quad per slot, the pair in the constants (cycle_body, UNI)
+    const bool uni = fastf && !fun && a.uni;
     // LEAN launches touch only the head of the region.  They ask for no more than that while the launch is at most one
     // wave per SIMD (C5 -2 %, C3N -0.6 %, C3 +-0 at 65 536 arms); beyond, the full size keeps the launch in rounds of one
     // wave per SIMD -- with eight waves resident per CU a 131 072-arm launch took 12.5 instead of 11.0 us (two waves
@@ -2670,26 +2703,26 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                     const size_t lds2 = (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ);
                     constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                     if (NS && a.flags == (unsigned)NSMIX)
-                        launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2>(a, grid, blk, lds2, stream);
+                        { if (uni) launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
                     else if (NS && a.flags == (unsigned)NSJLMIX)
-                        launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2>(a, grid, blk, lds2, stream);
+                        { if (uni) launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
                     else
-                        launch_lean<T, NJ, NS, PL, -1, false, false, 2>(a, grid, blk, lds2, stream);
+                        { if (uni) launch_lean<T, NJ, NS, PL, -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
                     return;
                 }
             }
             if constexpr (NS && NJ <= 7) {  // the flag sets of the default process set, as compile-time constants
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    launch_lean<T, NJ, NS, PL, NSMIX>(a, grid, blk, lds_lean, stream);
+                    { if (uni) launch_lean<T, NJ, NS, PL, NSMIX, false, false, 1, true>(a, grid, blk, lds_lean, stream); else launch_lean<T, NJ, NS, PL, NSMIX, false, false, 1, false>(a, grid, blk, lds_lean, stream); }
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    launch_lean<T, NJ, NS, PL, NSJLMIX>(a, grid, blk, lds_lean, stream);
+                    { if (uni) launch_lean<T, NJ, NS, PL, NSJLMIX, false, false, 1, true>(a, grid, blk, lds_lean, stream); else launch_lean<T, NJ, NS, PL, NSJLMIX, false, false, 1, false>(a, grid, blk, lds_lean, stream); }
                     return;
                 }
             }
-            launch_lean<T, NJ, NS, PL>(a, grid, blk, lds_lean, stream);
+            { if (uni) launch_lean<T, NJ, NS, PL, -1, false, false, 1, true>(a, grid, blk, lds_lean, stream); else launch_lean<T, NJ, NS, PL, -1, false, false, 1, false>(a, grid, blk, lds_lean, stream); }
             return;
         }
         if constexpr (NJ > VFIK_ROLL_MAX_NJ) {  // a cycle of a stepped rollout: lean, but it integrates q on the way out
@@ -2711,15 +2744,15 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             if constexpr (NS && NJ <= 7) {
                 constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
                 if (a.flags == (unsigned)NSMIX) {
-                    launch_full<T, NJ, NS, PL, false, true, 3, NSMIX>(a, grid, blk, lds_lean, stream);
+                    { if (uni) launch_full<T, NJ, NS, PL, false, true, 3, NSMIX, false, false, true>(a, grid, blk, lds_lean, stream); else launch_full<T, NJ, NS, PL, false, true, 3, NSMIX, false, false, false>(a, grid, blk, lds_lean, stream); }
                     return;
                 }
                 if (a.flags == (unsigned)NSJLMIX) {
-                    launch_full<T, NJ, NS, PL, false, true, 3, NSJLMIX>(a, grid, blk, lds_lean, stream);
+                    { if (uni) launch_full<T, NJ, NS, PL, false, true, 3, NSJLMIX, false, false, true>(a, grid, blk, lds_lean, stream); else launch_full<T, NJ, NS, PL, false, true, 3, NSJLMIX, false, false, false>(a, grid, blk, lds_lean, stream); }
                     return;
                 }
             }
-            launch_full<T, NJ, NS, PL, false, true, 3>(a, grid, blk, lds_lean, stream);
+            { if (uni) launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, true>(a, grid, blk, lds_lean, stream); else launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, false>(a, grid, blk, lds_lean, stream); }
             return;
         }
     }

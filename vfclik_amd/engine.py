@@ -80,6 +80,7 @@ def load_library(path=None):
         "vfik_time_steps": (C.c_int, [H, C.POINTER(IO), C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "vfik_slots_in_use": (C.c_int, [H]),
         "vfik_field_path": (C.c_int, [H]),
+        "vfik_uniform_repellers": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
         "vfik_host_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_host_free": (C.c_int, [H, C.c_void_p]),
@@ -235,6 +236,11 @@ class Engine:
     def field_path(self):
         """0 general, 1 straight-line (goal + decay repellers of one integer order), 2 straight-line with an aux block (one funnel and / or one hemisphere per arm)."""
         return self.lib.vfik_field_path(self.h)
+
+    @property
+    def uniform_repellers(self):
+        """True when every decay repeller of the batch shares one safe distance and one force (the uniform repeller image is read)."""
+        return bool(self.lib.vfik_uniform_repellers(self.h))
 
     @property
     def device_bytes(self):
