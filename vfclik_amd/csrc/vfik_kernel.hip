@@ -760,6 +760,9 @@ template <typename T> struct SlotLds {
 // phase, q round trip and tail.
 // Lean single-cycle launches on the straight-line path take the 56-byte KLean instead of the 340-byte KArgs (vfik_kernel.h): the
 // handle's state is one arena whose layout follows from (io type, joints, Bpad).  (The diagnostic stamps build keeps KArgs.)
+#ifndef VFIK_Q_FIRST
+#define VFIK_Q_FIRST 0            // 1: q's pieces requested in front of the constants (A/B builds: no gain, profiles/r03_ab_experiments.md 18)
+#endif
 #ifndef VFIK_NT_STORES
 #define VFIK_NT_STORES 0          // 1: the lane-by-lane output stores non-temporal (A/B builds)
 #endif
@@ -871,6 +874,24 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     constexpr int QB = Stage<T>::QBYTES, Q16 = Stage<T>::Q16;
     constexpr int PRE = Stage<T>::PRE;
     const long planeB = Bp * QB;  // bytes of one quad plane
+    constexpr int NQREQ = Stage<T>::q16(NJ) + Stage<T>::qrem(NJ) / 4;   // requests that bring one q vector
+    auto issue_q_piece = [&](int r, int armx, char* dr) {  // piece r of arm armx's q into the per-arm area dr
+        const char* qg = static_cast<const char*>(a.q) + (long)armx * NJ * sizeof(T);
+        char* qrow = dr + Stage<T>::Q_OFF;
+        constexpr int n16 = Stage<T>::q16(NJ);
+        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
+    };
+    // (Round 3 tried q's pieces FIRST, in front of the constants -- q is the one input the wave cannot start without, and with the
+    // inputs in HBM the one it waits for longest: C3 / C3N +-0.1 % cold and warm, C5 +0.9 % cold.  Two requests earlier is nothing
+    // against a round trip.)
+    constexpr bool QFIRST = VFIK_Q_FIRST && !PERS;
+    if constexpr (QFIRST) {
+        if (arm < a.B) {
+#pragma unroll
+            for (int r = 0; r < NQREQ; ++r) issue_q_piece(r, arm, dreg);
+        }
+    }
     {   // kinematics constants (oldest request: covered by the first wait).  All 64 lanes copy
         // 16 bytes each, so this comes before the lanes past the end of the batch retire.
         const char* kg = static_cast<const char*>(a.kc) + lane * 16;
@@ -901,16 +922,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
         for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
-    constexpr int NQREQ = Stage<T>::q16(NJ) + Stage<T>::qrem(NJ) / 4;   // requests that bring one q vector
-    auto issue_q_piece = [&](int r, int armx, char* dr) {  // piece r of arm armx's q into the per-arm area dr
-        const char* qg = static_cast<const char*>(a.q) + (long)armx * NJ * sizeof(T);
-        char* qrow = dr + Stage<T>::Q_OFF;
-        constexpr int n16 = Stage<T>::q16(NJ);
-        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
-    };
+    if constexpr (!QFIRST) {
 #pragma unroll
-    for (int r = 0; r < NQREQ; ++r) issue_q_piece(r, arm, dreg);
+        for (int r = 0; r < NQREQ; ++r) issue_q_piece(r, arm, dreg);
+    }
     // The goal and slot requests are issued later, between the joints of the kinematics: a load costs
     // the issuing wave ~50 cycles while the CU's four waves queue on the one address unit
     // (tools/ubench_loads.hip), and spreading them out lets that queue drain under arithmetic.
