@@ -120,7 +120,9 @@ struct vfik_handle {
     // vfik_step_host / vfik_rollout_host: one device arena + one pinned host arena for every member of the call
     void* arena_dev = nullptr;
     void* arena_host = nullptr;
+    void* arena_host_dev = nullptr;   // the device's address of the pinned host arena (zero-copy calls)
     size_t arena_bytes = 0;
+    size_t zero_copy_max = (size_t)64 << 10;   // calls of at most this many bytes: the kernel reads / writes the pinned arena itself (VFIK_ZERO_COPY_MAX)
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     Scratch sc[20];  // ... and per-member device buffers for calls of few large members
     // pipelined host path (vfik_submit_host / vfik_wait): up to PIPE submissions in flight, each slot with
@@ -399,6 +401,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_TWO_WAVES")) h->waves2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_UNIFORM_IMAGE")) h->uni_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VFIK_ZERO_COPY_MAX")) h->zero_copy_max = (size_t)std::max(0L, std::atol(e));
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
@@ -1001,12 +1004,17 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
         h->arena_dev = h->arena_host = nullptr;
         h->arena_bytes = 0;
         const size_t cap = total + total / 4 + 4096;
-        if (hipMalloc(&h->arena_dev, cap) != hipSuccess || hipHostMalloc(&h->arena_host, cap, hipHostMallocDefault) != hipSuccess)
+        if (hipMalloc(&h->arena_dev, cap) != hipSuccess || hipHostMalloc(&h->arena_host, cap, hipHostMallocMapped) != hipSuccess)
             return fail(VFIK_E_HIP, "arena allocation of %zu bytes failed", cap);
+        if (hipHostGetDevicePointer(&h->arena_host_dev, h->arena_host, 0) != hipSuccess) { (void)hipGetLastError(); h->arena_host_dev = nullptr; }
         h->arena_bytes = cap;
     }
     char* const hostA = static_cast<char*>(h->arena_host);
-    char* const devA = static_cast<char*>(h->arena_dev);
+    // A handful of arms (what vfclik itself runs: one arm per process set): no copy at all -- the kernels read the inputs from, and write
+    // the outputs to, the pinned arena over the bus.  Two copy submissions and their DMA round trips cost such a call more than the
+    // kernel's few PCIe transactions (ccb_rate: one arm, qdot_out only 23 -> 17 us; profiles/r03_ccb_rate.txt).
+    const bool zero_copy = total <= h->zero_copy_max && h->arena_host_dev;
+    char* const devA = zero_copy ? static_cast<char*>(h->arena_host_dev) : static_cast<char*>(h->arena_dev);
     void* din[N_HIN] = {};
     void* dout[N_HOUT] = {};
     for (int i = 0; i < N_HIN; ++i)
@@ -1018,12 +1026,12 @@ static int cycles_host(vfik_handle* h, const vfik_io* io, int n_cycles, double d
             // gated arms store nothing: their rows of the caller's arrays must come back as they went in
             if (io->active) { std::memcpy(hostA + off_out[i], x.hout[i], x.bout[i]); h2d = total; }
         }
-    HIP_TRY(hipMemcpyAsync(devA, hostA, h2d, hipMemcpyHostToDevice, h->stream));
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(devA, hostA, h2d, hipMemcpyHostToDevice, h->stream));
     vfik_io d;
     device_io(din, dout, d);
     const int rc = n_cycles > 0 ? vfik_rollout(h, &d, n_cycles, dt, clamp, dout[8]) : vfik_step(h, &d);
     if (rc != VFIK_OK) return rc;
-    if (total > in_bytes) HIP_TRY(hipMemcpyAsync(hostA + in_bytes, devA + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!zero_copy && total > in_bytes) HIP_TRY(hipMemcpyAsync(hostA + in_bytes, devA + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int i = 0; i < N_HOUT; ++i)
         if (x.hout[i]) std::memcpy(x.hout[i], hostA + off_out[i], x.bout[i]);
