@@ -663,10 +663,24 @@ typedef __attribute__((address_space(3))) void* LPtr;
 // Infinity Cache.  With the inputs coming from HBM (rotating input sets, bench.py --state cold) it is worth -6.8 % on C3
 // (6.62 -> 6.16 us) and -5.8 % on C5, at +0.8 % / -4.3 % in the cache-resident state: every chain uses it since round 3
 // (profiles/r03_nt_ab.txt).
+#ifndef VFIK_SADDR_REQUESTS
+#define VFIK_SADDR_REQUESTS 0     // 1: requests in the SGPR-base form (A/B builds: C5 +2.6 %, C3 +-0.5 % -- profiles/r03_ab_experiments.md 21)
+#endif
+// The address is (wave-uniform plane base) + (this lane's 32-bit byte offset).  Round 3 tried the SGPR-base form of the instruction
+// (`global_load_lds v_off, s[base]`: the offset unsigned and opaque, so that the backend reads base + zext(offset)): 30 of the 34 requests
+// take it, one 64-bit vector addition a request becomes two to three scalar instructions -- and a lone wave pays an issue slot for
+// either: C3 +-0.5 %, C5 +2.6 % warm / +1.8 % cold.  Off (VFIK_SADDR_REQUESTS); voff < 4 GiB either way.
 template <typename T, bool NT = false>
-__device__ __forceinline__ void stage_quad(const char* gsrc, char* region, int off) {
+__device__ __forceinline__ void stage_quad(const char* gbase, unsigned voff, char* region, int off) {
+#if VFIK_SADDR_REQUESTS
+    asm("" : "+v"(voff));   // (opaque: or the optimiser widens the offset's multiplication and the addition no longer reads base + zext(offset))
+    __builtin_amdgcn_global_load_lds((GPtr)(gbase + voff), (LPtr)(region + off), 16, 0, NT ? 2 : 0);
+    if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gbase + 16 + voff), (LPtr)(region + off + 1024), 16, 0, NT ? 2 : 0);
+#else
+    const char* gsrc = gbase + (long)(int)voff;
     __builtin_amdgcn_global_load_lds((GPtr)gsrc, (LPtr)(region + off), 16, 0, NT ? 2 : 0);
     if (Stage<T>::Q16 == 2) __builtin_amdgcn_global_load_lds((GPtr)(gsrc + 16), (LPtr)(region + off + 1024), 16, 0, NT ? 2 : 0);
+#endif
 }
 
 template <typename T>
@@ -876,11 +890,21 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     const long planeB = Bp * QB;  // bytes of one quad plane
     constexpr int NQREQ = Stage<T>::q16(NJ) + Stage<T>::qrem(NJ) / 4;   // requests that bring one q vector
     auto issue_q_piece = [&](int r, int armx, char* dr) {  // piece r of arm armx's q into the per-arm area dr
+#if VFIK_SADDR_REQUESTS
+        const char* const q0 = static_cast<const char*>(a.q);            // (uniform base + unsigned lane offset: stage_quad)
+        unsigned qv = (unsigned)armx * (unsigned)(NJ * sizeof(T));
+        asm("" : "+v"(qv));
+        char* qrow = dr + Stage<T>::Q_OFF;
+        constexpr int n16 = Stage<T>::q16(NJ);
+        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(q0 + r * 16 + qv), (LPtr)(qrow + r * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((GPtr)(q0 + (n16 * 16 + (r - n16) * 4) + qv), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
+#else
         const char* qg = static_cast<const char*>(a.q) + (long)armx * NJ * sizeof(T);
         char* qrow = dr + Stage<T>::Q_OFF;
         constexpr int n16 = Stage<T>::q16(NJ);
         if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, 0);
         else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
+#endif
     };
     // (Round 3 tried q's pieces FIRST, in front of the constants -- q is the one input the wave cannot start without, and with the
     // inputs in HBM the one it waits for longest: C3 / C3N +-0.1 % cold and warm, C5 +0.9 % cold.  Two requests earlier is nothing
@@ -913,14 +937,14 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     }
     if (a.active) act = a.active[arm];
     if (a.tool_stride) {          // per-arm tools ([3][Bpad] quads); a shared tool sits in KConst
-        const char* tg = static_cast<const char*>(a.tool) + (long)arm * QB;
+        const char* tg = static_cast<const char*>(a.tool);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stage_quad<T, NTL>(tg + k * planeB, region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP);
+        for (int k = 0; k < 3; ++k) stage_quad<T, NTL>(tg + k * planeB, (unsigned)arm * (unsigned)QB, region, Stage<T>::tool_off(NJ) + k * Stage<T>::QSTEP);
     }
     if (a.mixw) {  // per-arm mixer weights ([2][Bpad] quads: w0..w3 | w4 w5 - -); else KConst::mix_w
-        const char* mg = static_cast<const char*>(a.mixw) + (long)arm * QB;
+        const char* mg = static_cast<const char*>(a.mixw);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
+        for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, (unsigned)arm * (unsigned)QB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
     if constexpr (!QFIRST) {
 #pragma unroll
@@ -938,7 +962,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     const char* const slots0 = static_cast<const char*>(FASTF ? a.slots_fast : a.slots);
     const char* sg = slots0 + (long)arm * QB;  // this arm's quad of slot plane 0
     auto issue_goal_quad = [&](int k, int armx, char* dr) {
-        stage_quad<T, NTL>(goal0 + (long)armx * QB + k * planeB, dr, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
+        stage_quad<T, NTL>(goal0 + k * planeB, (unsigned)armx * (unsigned)QB, dr, Stage<T>::GOAL_OFF + k * Stage<T>::QSTEP);
     };
     auto issue_slot_quad_of = [&](int idx, int armx, char* dr) {  // idx in [0, QPC): quad idx of the first chunk of slots
         // quads past the slots in use re-request plane 0 (cache hit) and are masked below, so the
@@ -946,7 +970,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
         // (Round 3 tried a wave-uniform fast path without the per-quad compare / select when every slot of the window is in use --
         // ~60 fewer scalar instructions a wave: C3 +1.2 % warm, +0.3 % cold, C5 +-0.1 %; scalar work is not what a lone wave waits for.)
         const bool in = UNI ? idx < npre : (FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre);
-        stage_quad<T, NTL>(slots0 + (long)armx * QB + (in ? (long)idx * planeB : 0), dr, Stage<T>::slot_off(idx, NJ));
+        stage_quad<T, NTL>(slots0 + (in ? (long)idx * planeB : 0), (unsigned)armx * (unsigned)QB, dr, Stage<T>::slot_off(idx, NJ));
     };
     auto issue_slot_quad = [&](int idx) { issue_slot_quad_of(idx, arm, dreg); };
     constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
@@ -967,9 +991,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
     if constexpr (FUN) {  // the funnel block, right behind the goal block: the goal's wait covers it
-        const char* fg = static_cast<const char*>(a.funnel) + (long)arm * QB;
+        const char* fg = static_cast<const char*>(a.funnel);
 #pragma unroll
-        for (int k = 0; k < NFUN; ++k) stage_quad<T, NTL>(fg + k * planeB, region, FUN_OFF + k * Stage<T>::QSTEP);
+        for (int k = 0; k < NFUN; ++k) stage_quad<T, NTL>(fg + k * planeB, (unsigned)arm * (unsigned)QB, region, FUN_OFF + k * Stage<T>::QSTEP);
     }
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
@@ -1490,8 +1514,8 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
                     for (int idx = 0; idx < QPC; ++idx) {
                         const int m = UNI ? c0 + PRE + idx : c0 + PRE + 2 * (idx / 3);  // (first) slot of the quad
-                        const char* sm = sg + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
-                        stage_quad<T, NTL>(sm, dreg, Stage<T>::slot_off(idx, NJ));
+                        const char* sm = slots0 + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
+                        stage_quad<T, NTL>(sm, (unsigned)arm * (unsigned)QB, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 double di[PRE], rb[PRE], rp[PRE];
@@ -1547,8 +1571,8 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
                     for (int idx = 0; idx < 2 * PRE; ++idx) {
                         const int m = c0 + (idx >> 1);
-                        const char* sm = sg + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
-                        stage_quad<T, NTL>(sm, dreg, Stage<T>::slot_off(idx, NJ));
+                        const char* sm = slots0 + (m < a.slots_used ? (long)m * 2 * planeB : 0) + (idx & 1) * planeB;
+                        stage_quad<T, NTL>(sm, (unsigned)arm * (unsigned)QB, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                 }
                 VFIK_WAIT_VM(0);
