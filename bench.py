@@ -362,7 +362,8 @@ def worker(args):
         """R repetitions of the timed region; returns (wall seconds per WALL repetition, enqueue seconds, HIP-event ms per EVENT
         repetition).  Repetitions alternate between two kinds: WALL repetitions (even) carry nothing but the K launches between
         the stamps and give `value`; EVENT repetitions (odd) bracket the same K launches with HIP events on the launch stream
-        and give the kernel's launch period for `roofline`.  (Recording two timing events costs a 20-launch region ~20 us --
+        and give the kernel's launch period for `roofline` (with one priming launch in front of the first event, so that all K
+        timed launches run back to back whatever K is).  (Recording two timing events costs a 20-launch region ~20 us --
         1 us a step -- which is why they are kept out of the interval that `value` comes from.)  Launch i of a repetition
         goes to input set i mod len(active_sets): one set = back-to-back launches over the same bytes (cache-resident),
         many = every launch finds its inputs in HBM."""
@@ -378,6 +379,10 @@ def worker(args):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if with_events:
+                # one priming launch in front of the first event: the K launches between the events then run back to back, the
+                # first of them included (a kernel that starts on an idle queue takes 0.7-1.6 us longer, profiles/r03_trace_gaps.txt:
+                # at 20 launches per region that bias was 0.4 us per launch).  EVENT repetitions only; `value` never sees it.
+                steppers[(ns - 1) % ns]()
                 ev0.record(stream)
             if graph is not None:
                 graph.replay()
@@ -572,7 +577,7 @@ def worker(args):
                          "algorithmic_bytes_per_cycle": bytes_per_cycle,
                          "us_per_launch_hip_events": us_med,
                          "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),
-                         "launches_timed": R * K, "timed": "R repetitions of K launches between two HIP events on the launch stream, interleaved with the wall-clock repetitions"},
+                         "launches_timed": R * K, "timed": "R repetitions of K launches between two HIP events on the launch stream (one untimed priming launch in front of the first event), interleaved with the wall-clock repetitions"},
         }
         if args.sync_each:
             line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"
