@@ -80,7 +80,10 @@ C3N 2 013 / 2 457, C5 3 457 / 4 049.  C2's and C2F's kernels are the eight-lanes
   `%(R)s_stamps_131072_arms_in_rounds.txt`.  Field paths: `%(R)s_general_path.txt`.
 * Drop-in path: `%(R)s_ccb_rate.txt` (ControlCycleBatch.cycle() with ports / step_arrays with every output / qdot_out only).
 * Stamps (diagnostic build): `%(R)s_stamps_C3_{warm,cold}.txt`, `%(R)s_stamps_C3N_{warm,cold}.txt`, `%(R)s_stamps_C3F_warm.txt`.
-* A/B log: `%(R)s_ab_experiments.md` with its raw files.
+* A/B log: `%(R)s_ab_experiments.md` with its raw files (`%(R)s_ab_*.txt`): preloaded scalar kernel arguments, uniform repeller image, two waves per
+  SIMD, aux block, and the rejected ones (nt output stores, block size, q first, SGPR-base requests, iterative-ilp scheduling, ...).
+* Independent batches in flight on one GPU: `%(R)s_two_handles.txt`; host-pointer calls without a copy: `%(R)s_ccb_rate_zero_copy_ab.txt`;
+  field paths: `%(R)s_general_path.txt`; traced durations against launch cadence: `%(R)s_trace_gaps.txt`.
 """ % dict(R=R, rnd=rnd, tag=tag, table=table, traffic=traffic, sq=sq)
 open(os.path.join(ROOT, "profiles", "%s_summary.md" % R), "w").write(txt)
 print("wrote profiles/%s_summary.md" % R)
