@@ -266,16 +266,48 @@ def worker(args):
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = args.dist_backend
+    backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The control path has no collective: the process group only carries the barrier in front of each timed region, the max over
+        # ranks of the timings and the optional gather.  One store for the job; RCCL is initialised eagerly (device_id), so that a
+        # rank that cannot bring its communicator up says so HERE -- then EVERY rank falls back to gloo for those three (decided
+        # through the store), instead of the job dying without a line.
+        # (the store of the env:// rendezvous: under torch.distributed.run the launcher's agent hosts it, under bench.py's own
+        # launcher rank 0 does)
+        store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
+        if backend == "nccl":
+            ok, why = 1, ""
+            try:
+                if os.environ.get("VFIK_BENCH_FAIL_NCCL") == "1":
+                    raise RuntimeError("VFIK_BENCH_FAIL_NCCL=1 (rehearsal of the fallback)")
+                dist.init_process_group("nccl", store=dist.PrefixStore("nccl", store), rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+                t = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t)           # the communicator really works
+                torch.cuda.synchronize()
+                ok = 1 if int(t.item()) == world else 0
+            except Exception as e:  # noqa: BLE001 -- whatever RCCL / c10d raise
+                ok, why = 0, (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+            store.set("nccl_ok_%d" % rank, str(ok))
+            all_ok = all(store.get("nccl_ok_%d" % r) == b"1" for r in range(world))   # (get blocks until the key exists)
+            if not all_ok:
+                if dist.is_initialized():
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                backend = "gloo"
+                backend_note = "gloo (RCCL communicator not available on every rank%s): barrier / timing reductions on the CPU" % (": " + why if why else "")
+                print("[bench] rank %d: falling back to gloo for the barrier and the timing reductions%s" % (rank, ": " + why if why else ""), file=sys.stderr)
+                dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
 
     tdt = torch.float32 if io_dtype == np.float32 else torch.float64
     dev = torch.device("cuda", local_rank)
-    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the timing reductions run
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the timing reductions run
     # the launch stream: a stream of its own (not the legacy default stream), so that the K launches of a region can also be captured into a hipGraph
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -521,7 +553,7 @@ def worker(args):
     gathered = None
     if args.gather and world > 1:
         # optional collation of the per-rank results (NOT part of the control path): one all_gather
-        src = qdot if args.dist_backend == "nccl" else qdot.cpu()
+        src = qdot if backend == "nccl" else qdot.cpu()
         gathered = sharded[0].gather(src)   # sharding.collate: one all_gather over xGMI (RCCL), gloo in the rehearsal
 
     if rank == 0:
@@ -593,6 +625,8 @@ def worker(args):
                 **{st: {k: ktrace[st].get(k) for k in ("mean_ns", "median_ns", "min_ns", "dispatches", "frac")} for st in ("warm", "cold") if st in ktrace}}
         if extra_outs:
             line["config"]["outputs"] = ["qdot_out"] + list(extra_outs)
+        if world > 1:
+            line["config"]["process_group"] = backend_note or ("nccl (RCCL): barrier and timing reductions only" if backend == "nccl" else "gloo")
         if per_rank_ms is not None:
             line["per_rank_ms_per_step"] = per_rank_ms
             line["config"]["rank0_cpu_binding"] = binding

@@ -162,3 +162,21 @@ def test_output_rows_through_unaligned_pointers_and_partial_waves():
     for k in shapes:
         assert np.array_equal(res[0][k], res[1][k]), k
     assert np.abs(res[0]["pose"][:, 15] - 1.0).max() == 0.0 and np.abs(res[0]["qdot_out"]).max() > 1e-3
+
+
+def test_bench_two_ranks_fall_back_to_gloo_when_rccl_cannot_start():
+    """`bench.py --gpus 2` on ONE device: RCCL refuses two ranks on one GPU, so this is the rehearsal of a communicator that does not
+    come up -- every rank must agree (through the store) on gloo for the barrier and the timing reductions, and the job must still
+    print its line.  (The control path itself has no collective.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-device", "--steps", "10", "--warmup", "3", "--reps", "3",
+                          "--no-cpu-baseline", "--rollout", "0", "--host-path", "0", "--state", "warm"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 1e9
+    assert line["config"]["process_group"].startswith("gloo (RCCL communicator not available"), line["config"]["process_group"]
+    assert line["max_abs_err_rad_s"] < 1e-6
