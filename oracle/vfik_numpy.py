@@ -390,7 +390,17 @@ class CommandMixer:
         return result
 
 
-def limiter(qdot, max_vel):  # LWR_Bridge.set_vel, bridge:188-195
+def get_weight_matrix(wbottle, n_vars):  # vf:164-179; pinned by tests/golden/weights_golden.npz
+    """Diagonal (n_vars, n_vars) weight matrix from a ('t' | 'j', w_0 ... w_{n_vars-1}) bottle, None for any other size."""
+    if wbottle.size() != n_vars + 1:
+        return None
+    W = np.zeros((n_vars, n_vars))
+    for i in range(n_vars):
+        W[i, i] = wbottle.get(i + 1).asDouble()
+    return W
+
+
+def limiter(qdot, max_vel):  # LWR_Bridge.set_vel, bridge:188-195; pinned by tests/golden/bridge_golden.npz
     lead = max(abs(v) for v in qdot)
     ratio = max_vel / lead if lead > max_vel else 1.0
     return [v * ratio for v in qdot], lead > max_vel

@@ -146,3 +146,42 @@ def test_kept_reference_equals_the_reference_clamp(env, golden_dir):
         assert np.array_equal(got["q_ref_out"], want), robot
         assert np.abs(got["qdot_out"] - (want - q)).max() < 1e-12   # channel 2 alone: kp (clamp(ref) - q), kp = 1
         eng.close()
+
+
+@pytest.mark.parametrize("robot,dt", [("lwr", np.float64), ("lwr", np.float32), ("lwr_dual14", np.float64), ("powercube6", np.float64)])
+def test_limiter_and_lwr_command_form_equal_the_reference_record(env, golden_dir, robot, dt):
+    """The fused limiter + LWR command form against what `LWR_Bridge.set_vel` of the REFERENCE returned for the same numbers
+    (tests/golden/bridge_golden.npz, made by running bridge:182-210; make_golden_blocks.py).  The record's joint velocities go in
+    as the /bridge/mechanismcmd channel with mixer weights [0,0,0,1,0,0], each arm with its record's max_vel, last_q as q and
+    last_qcmded as the robot's echo; `direct_control` arms have every mixer weight 0 (bridge:604), which makes their mixed command
+    0 -- so of the record's direct cases only those with a zero command are reachable through the bridge loop, and only those are
+    compared here (the others pin the CPU oracles, tests/test_reference_blocks.py)."""
+    import os
+    abi = env["abi"]
+    chain = env["robots"].by_name(robot)
+    g = np.load(os.path.join(golden_dir, "bridge_golden.npz"))
+    sel = np.nonzero((g["n"] == chain.n) & (~g["direct"] | (np.nan_to_num(np.abs(g["qdot"])).max(axis=1) == 0.0)))[0]
+    B = len(sel)
+    assert B >= 40 and g["direct"][sel].sum() >= 4
+    n = chain.n
+    qdot, q, qc, exp = (g[k][sel, :n].astype(dt).astype(np.float64) for k in ("qdot", "last_q", "last_qcmded", "cmd"))
+    mv = g["max_vel"][sel].astype(dt).astype(np.float64)
+    if dt == np.float32:    # the kernel sees float32-rounded inputs: restate bridge:188-203 on those (the oracle is pinned bit-exact)
+        exp = np.array([env["vn"].lwr_command(env["vn"].limiter(qdot[b].tolist(), float(mv[b]))[0],
+                                              q[b].tolist(), qc[b].tolist(), bool(g["direct"][sel][b])) for b in range(B)])
+    w = env["synth"].make_workload(chain, B, 1, seed=2, io_dtype=dt)
+    params = abi.default_params(flags=abi.F_MIXER | abi.F_LIMITER, max_vel=1.0)
+    eng = env["engine"].Engine(chain, B, io_dtype=dt, max_slots=4, device=0, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    mixw = np.tile(np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0]), (B, 1))
+    mixw[g["direct"][sel]] = 0.0
+    eng.set_mixer_weights(mixw)
+    eng.set_max_vel(g["max_vel"][sel])
+    eng.set_ext_cmd(3, qdot)
+    got = eng.step_host(q, q_cmded=qc, want=("qdot_out", "status"))
+    err = np.abs(got["qdot_out"] - exp).max()
+    assert err < (1e-12 if dt == np.float64 else 5e-7), err
+    scaled = np.abs(qdot).max(axis=1) > mv
+    assert 5 < scaled.sum() < B - 5
+    assert np.array_equal((got["status"] & abi.ST_LIMITED) != 0, scaled)
+    eng.close()

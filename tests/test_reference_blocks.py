@@ -1,0 +1,245 @@
+"""Oracle and host layer against records produced by RUNNING blocks of the reference (tests/golden/make_golden_blocks.py):
+get_weight_matrix (vf:164-179), LWR_Bridge.set_vel (bridge:182-210), the handler methods of src/handlers.py, the tracking-state
+vote of scripts/monitor_distance:168-219 and the object feeder's loop (object_feeder:93-359).  CPU only; the GPU side of the
+bridge record is tests/test_gpu_joint_controller.py::test_limiter_and_lwr_command_form_equal_the_reference_record."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vfik_numpy as vn
+from vfclik_amd import handlers
+from vfclik_amd import ports as yarp
+from vfclik_amd.object_feeder import ObjectFeeder
+from vfclik_amd.vf_module import TrackingState, parse_weight_bottle
+
+
+@pytest.fixture(autouse=True)
+def fresh_network():
+    yarp.Network.reset()
+    yield
+    yarp.Network.reset()
+
+
+def _tagged(b):
+    """A ports.Bottle as the fixture writes bottles: [[tag, value], ...] with d / i / s / l tags."""
+    out = []
+    for k in range(b.size()):
+        v = b.get(k)
+        if v.isList():
+            out.append(["l", _tagged(v.asList())])
+        elif v.isString():
+            out.append(["s", v.asString()])
+        elif v.isInt():
+            out.append(["i", v.asInt()])
+        else:
+            assert v.isDouble()
+            out.append(["d", v.asDouble()])
+    return out
+
+
+def _from_tagged(items):
+    b = yarp.Bottle()
+    for tag, v in items:
+        if tag == "l":
+            b.add(yarp.Value(_from_tagged(v)))
+        elif tag == "s":
+            b.addString(v)
+        elif tag == "i":
+            b.addInt(v)
+        else:
+            b.addDouble(v)
+    return b
+
+
+# ---- A2: get_weight_matrix -----------------------------------------------------------------------------
+def test_weight_bottles_against_the_reference_record(golden_dir):
+    g = np.load(os.path.join(golden_dir, "weights_golden.npz"))
+    C = len(g["kind"])
+    assert C == 45 and g["accepted"].sum() == 9
+    for c in range(C):
+        kind = "t" if g["kind"][c] == 0 else "j"
+        ln, n_vars = int(g["length"][c]), int(g["n_vars"][c])
+        vals = [int(v) if i else float(v) for v, i in zip(g["values"][c, :ln], g["is_int"][c, :ln])]
+        b = yarp.Bottle([kind] + vals)
+        # oracle restatement
+        W = vn.get_weight_matrix(b, n_vars)
+        assert (W is not None) == bool(g["accepted"][c])
+        if W is not None:
+            assert np.array_equal(W, g["W"][c, :n_vars, :n_vars])
+        # host parser: the joint count decides n_vars for 'j', 6 for 't' (vf:299-309)
+        parsed = parse_weight_bottle(b, n_vars if kind == "j" else 7)
+        assert parsed is not None and parsed[0] == kind
+        if g["accepted"][c]:
+            assert np.array_equal(np.diag(parsed[1]), g["W"][c, :n_vars, :n_vars])
+        else:
+            assert parsed[1] is None
+    assert parse_weight_bottle(yarp.Bottle(["x", 1.0]), 7) is None
+    assert parse_weight_bottle(yarp.Bottle([]), 7) is None
+
+
+# ---- (f)-1: limiter + LWR command form -------------------------------------------------------------------
+def test_bridge_set_vel_oracles_bit_exact(golden_dir, oracle_c):
+    g = np.load(os.path.join(golden_dir, "bridge_golden.npz"))
+    C = len(g["n"])
+    assert C == 144 and g["direct"].sum() >= 30
+    scaled = 0
+    for c in range(C):
+        n = int(g["n"][c])
+        qdot, q, qc, exp = (g[k][c, :n] for k in ("qdot", "last_q", "last_qcmded", "cmd"))
+        lim, was = vn.limiter(qdot.tolist(), float(g["max_vel"][c]))
+        scaled += was
+        got = vn.lwr_command(lim, q.tolist(), qc.tolist(), bool(g["direct"][c]))
+        assert np.array_equal(np.array(got), exp), c
+        # the C oracle
+        v = qdot.copy()
+        oracle_c.lib().vfo_limiter(v.ctypes.data_as(oracle_c.C.c_void_p), oracle_c.C.c_int(n), oracle_c.C.c_double(float(g["max_vel"][c])))
+        got_c = oracle_c.lwr_cmd(v[None], q[None], qc[None], np.array([bool(g["direct"][c])]))[0]
+        assert np.array_equal(got_c, exp), c
+    assert 40 < scaled < 110   # both branches of bridge:191-194 are in the record
+
+
+# ---- (b): handler wire format ------------------------------------------------------------------------------
+class _Tap(yarp.BufferedPortBottle):
+    """Reader that keeps every delivery with the strictness the WRITER asked for."""
+
+    def __init__(self, name, log, key):
+        yarp.BufferedPortBottle.__init__(self)
+        self.open(name)
+        self.log, self.key = log, key
+
+    def _deliver(self, bottle, strict):
+        self.log.append({"port": self.key, "strict": bool(strict), "bottle": _tagged(bottle)})
+
+
+class _Scripted:
+    """Stands where a handler's input port is: hands out the fixture's scripted reads."""
+
+    def __init__(self, script):
+        self.script = [None if b is None else _from_tagged(b) for b in script]
+
+    def read(self, wait=True):
+        return self.script.pop(0) if self.script else None
+
+    def getPendingReads(self):
+        return 0
+
+
+class _Clock:
+    def __init__(self):
+        self.now = 100.0
+
+    def time(self):
+        return self.now
+
+    def sleep(self, s):
+        self.now += s
+
+
+def _unjson(v):
+    if isinstance(v, dict) and "ndarray" in v:
+        return np.array(v["ndarray"])
+    if isinstance(v, dict) and "npscalar" in v:
+        return getattr(np, v["npscalar"])(v["value"])
+    if isinstance(v, list):
+        return [_unjson(x) for x in v]
+    return v
+
+
+def _make_handler(cls_name, rec):
+    if cls_name == "HandleArmNew":
+        h = handlers.HandleArmNew()
+    elif cls_name == "HandleArm":
+        h = handlers.HandleArm("/lwr/right", namespace="/0")
+    elif cls_name == "HandleBridge":
+        torso = not (rec["method"] == "torso_joints" and not rec["writes"])
+        h = handlers.HandleBridge("/0/lwr/right", torso=torso)
+    else:
+        h = handlers.HandleJController("/0/lwr/right")
+    return h
+
+
+def test_handler_bottles_value_for_value_and_type_for_type(golden_dir, monkeypatch):
+    doc = json.load(open(os.path.join(golden_dir, "handlers_wire.json")))
+    clock = _Clock()
+    monkeypatch.setattr(handlers, "time", clock)
+    seen = set()
+    for rec in doc["records"]:
+        yarp.Network.reset()
+        h = _make_handler(rec["class"], rec)
+        log = []
+        # one tap behind every output port of the handler, keyed by the ATTRIBUTE name the reference uses for that port
+        for attr, port in vars(h).items():
+            if isinstance(port, yarp.BufferedPortBottle):
+                for k, dst in enumerate(sorted(yarp._REG.links.get(port.getName(), ()))):
+                    if k == 0:   # (HandleBridge wires both spellings of /bridge/weight(s): one tap is enough)
+                        _Tap(dst, log, attr)
+        if rec["class"] == "HandleArmNew" and rec["method"] == "get_dist_joint_goal":
+            h.joint_goal = [0.1, -0.2, 0.3, 1.1, -0.5, 0.7, 0.0]
+        for attr, script in rec["reads"].items():
+            setattr(h, attr, _Scripted(script))
+        clock.now = 100.0
+        ret = getattr(h, rec["method"])(*_unjson(rec["args"]), **_unjson(rec["kwargs"]))
+        exp = [{"port": w["port"], "strict": w["write"] != "write()", "bottle": w["bottle"]} for w in rec["writes"]]
+        assert log == exp, (rec["class"], rec["method"], rec["args"], log, exp)
+        want = _unjson(rec["returns"])
+        if isinstance(want, list) and len(want) == 2 and isinstance(want[0], bool):     # (result, difference)
+            assert ret[0] == want[0] and np.array_equal(np.asarray(ret[1]), np.asarray(want[1])), (rec["method"], ret, want)
+            assert abs((clock.now - 100.0) - rec["clock_advanced"]) < 1e-9, (rec["method"], clock.now)
+        elif want is None:
+            assert ret is None
+        else:
+            assert np.array_equal(np.asarray(ret), np.asarray(want)), (rec["method"], ret, want)
+        seen.add((rec["class"], rec["method"]))
+    assert len(seen) == 35 and len(doc["records"]) == 69
+
+
+# ---- (f)-3: tracking-state vote ------------------------------------------------------------------------------
+def test_tracking_state_messages_equal_the_reference_record(golden_dir):
+    doc = json.load(open(os.path.join(golden_dir, "tracking_state_golden.json")))
+    c = doc["constants"]
+    assert (TrackingState.distanceXYZ_th, TrackingState.track_error_xyz_th, TrackingState.distanceOrient_th,
+            TrackingState.track_error_rot_th, TrackingState.size) == \
+        (c["distanceXYZ_th"], c["track_error_xyz_th"], c["distanceOrient_th"], c["track_error_rot_th"], c["tracking_buffer_size"])
+    ts = TrackingState()
+    got = []
+    for t, row in enumerate(doc["samples"]):
+        for kind, state in ts.update(*row):
+            got.append([t, kind, state])
+    assert got == doc["messages"]
+    # the record holds the case the two votes differ in: a "rot" message whose payload is NOT the rot vote
+    assert [210, "rot", "on goal"] in got
+
+
+# ---- (f)-2 / A1: object feeder ---------------------------------------------------------------------------------
+def test_object_feeder_bottle_sequences_equal_the_reference_record(golden_dir):
+    doc = json.load(open(os.path.join(golden_dir, "feeder_wire.json")))
+    assert len(doc["scenarios"]) == 6
+    for name, sc in doc["scenarios"].items():
+        yarp.Network.reset()
+        base = "/0/lwr/right"
+        feeder = ObjectFeeder(base)
+        log = []
+        _Tap(base + "/vectorField/param", log, "param")
+        _Tap(base + "/dmonitor/objectsIn", log, "objectOut")
+        _Tap(base + "/tap/objectf", log, "objectf")
+        yarp.Network.connect(base + "/ofeeder/objectf", base + "/tap/objectf")
+        src = yarp.BufferedPortBottle()
+        src.open("/test/src")
+        yarp.Network.connect("/test/src", base + "/ofeeder/object")
+        exp = []
+        for ev in sc["events"]:
+            if "read" in ev:
+                b = src.prepare()
+                b.clear()
+                for tag, v in ev["read"]:
+                    b.add(yarp.Value(_from_tagged(v)) if tag == "l" else v)
+                src.writeStrict()
+                assert feeder.spin_once() == 1
+            else:
+                assert ev["write"] == "writeStrict()"
+                exp.append({"port": ev["port"], "strict": True, "bottle": ev["bottle"]})
+        assert log == exp, name
+        assert sorted(feeder.objects) == sc["objects_left"], name
+        feeder.close()

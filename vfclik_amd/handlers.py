@@ -12,12 +12,15 @@ never block (``yarp_connect_blocking`` -> ``ports.Network.connect``); methods th
 reference (``set_vf_tool``, ``set_stiffness`` of HandleArmNew, ``go_xyz``, ``go_rot``, ``get_joint_angles``)
 are empty here too.
 """
+import logging
 import time
 from math import pi
 
 import numpy as np
 
 from . import ports as yarp
+
+log = logging.getLogger("vfclik_amd.handlers")
 
 
 def _open(name, strict=False):
@@ -105,7 +108,15 @@ class HandleArmNew:
         self.set_cartesian_control()
 
     def _write_yarp_port(self, port, data, strict=True):  # handlers.py:132-145
-        _emit(port, [d for d in data if isinstance(d, (float, int, str, np.floating, np.integer))], strict)
+        """The reference adds a value only when its type is EXACTLY float, int or str (`type(i)==float`, handlers.py:136-141):
+        NumPy scalars, bools and None are dropped without a word, so `go_joint(numpy_array)` sends an EMPTY bottle there
+        (which /jpctrl/ref ignores).  Reproduced value for value and type for type (tests/golden/handlers_wire.json); the
+        only addition is the warning."""
+        kept = [d for d in data if type(d) in (float, int, str)]
+        if len(kept) != len(data):
+            log.warning("%d of %d values are not plain float / int / str and were dropped (handlers.py:136-141)",
+                        len(data) - len(kept), len(data))
+        _emit(port, kept, strict)
 
     def go_joint(self, angles):
         self.joint_goal = angles
@@ -152,8 +163,8 @@ class HandleArmNew:
     def set_wik_cart_weights(self, cart_weights):
         _emit(self.vf_weight_port, ["t"] + [float(w) for w in cart_weights])
 
-    def set_tool(self, tool_frame):
-        self._write_yarp_port(self.tool_port, [float(x) for x in tool_frame])
+    def set_tool(self, tool_frame):  # handlers.py:229-230: through the type filter, ints stay ints
+        self._write_yarp_port(self.tool_port, tool_frame)
 
 
 class HandleArm(object):
@@ -219,29 +230,29 @@ class HandleArm(object):
 
     def gotoFrame(self, frame, wait=10.0, goal_precision=[], spin=None):
         """frame: 16 values; wait in seconds; goal_precision [trans, rot] (handlers.py:346-387).
-        ``spin``: callable run while waiting (the in-process substitute for the other processes)."""
-        self.current_frame[:len(frame)] = [float(v) for v in frame]
+        ``spin``: callable run where the reference sleeps 10 ms (the in-process substitute for the other processes).
+        As in the reference, whatever the FIRST poll finds is discarded -- it is the report that was already waiting when the
+        goal went out (the reference counts the pending reads but does not read them, handlers.py:359-362) -- and `difference`
+        is the last report's."""
+        self.current_frame[:len(frame)] = [v for v in frame]
         self.sendFrame()
-        deadline = time.time() + wait
+        start = time.time()
         difference, result = np.array([0.0, 0.0]), False
-        while self.goaldistp.getPendingReads():  # stale reports
-            self.goaldistp.read(False)
-        skip_first = True  # the reference discards the first report after sending the goal
-        while len(goal_precision) == 2 and wait > 0.0 and time.time() < deadline:
-            if spin is not None:
-                spin()
-            else:
-                time.sleep(0.01)
-            b = self.goaldistp.read(False)
-            if b is None:
-                continue
-            entry = None if skip_first else _goal_entry(b)
-            skip_first = False
-            if entry is not None:
-                difference = np.array(entry)
-                if entry[0] < goal_precision[0] and entry[1] < goal_precision[1]:
-                    result = True
-                    break
+        if len(goal_precision) == 2 and wait > 0.0:
+            first_read = True
+            while time.time() - start < wait:
+                b = self.goaldistp.read(False)
+                entry = _goal_entry(b) if (b is not None and not first_read) else None
+                if entry is not None:
+                    difference = np.array(entry)
+                    if entry[0] < goal_precision[0] and entry[1] < goal_precision[1]:
+                        result = True
+                        break
+                first_read = False
+                if spin is not None:
+                    spin()
+                else:
+                    time.sleep(0.01)
         return (result, difference)
 
     def gotThere(self):
@@ -315,24 +326,23 @@ class HandleJController(object):
         yarp.Network.connect(prename + "/bridge/encoders", full_name + "/q")
 
     def set_ref_js(self, js, wait=0.0, goal_precision=[], spin=None):  # handlers.py:544-576
-        js = np.asarray(js, dtype=float)
-        _emit(self.outp, js.tolist())
+        _emit(self.outp, [float(v) for v in js])
         start = time.time()
-        difference, result = np.zeros(len(js)), False
-        if len(goal_precision) != len(js) or wait == 0.0:
-            return (result, difference)
-        tol = np.asarray(goal_precision, dtype=float)
-        while wait == -1 or time.time() - start < wait:  # wait == -1: until reached (handlers.py:559)
-            if spin is not None:
-                spin()
-            else:
-                time.sleep(0.01)
-            b = self.inp.read(False)
-            if b:
-                difference = js - np.array(_doubles(b))
-                if np.all(np.abs(difference) <= tol):
-                    result = True
-                    break
+        difference, result = np.array([0.0] * len(js)), False
+        if len(goal_precision) == len(js) and wait != 0.0:
+            tol = np.array(goal_precision)
+            while wait == -1 or time.time() - start < wait:  # wait == -1: until reached (handlers.py:559)
+                b = self.inp.read(False)
+                if b:
+                    q = np.array(_doubles(b))
+                    difference = js - q
+                    if (((js - tol) <= q) * ((js + tol) >= q)).all():
+                        result = True
+                        break
+                if spin is not None:
+                    spin()
+                else:
+                    time.sleep(0.01)
         return (result, difference)
 
 

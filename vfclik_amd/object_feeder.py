@@ -31,12 +31,14 @@ class ObjectFeeder:
         self.param_port = yarp.BufferedPortBottle()
         self.param_port.open(base + "/ofeeder/param")
         self.objects_out = yarp.BufferedPortBottle()
-        self.objects_out.open(base + "/ofeeder/objectsOut")
+        self.objects_out.open(base + "/ofeeder/objectOut")     # object_feeder:68
+        self.object_f_port = yarp.BufferedPortBottle()          # object_feeder:67,106-110: every /object bottle is forwarded
+        self.object_f_port.open(base + "/ofeeder/objectf")
         yarp.Network.connect(base + "/ofeeder/param", base + "/vectorField/param")
-        yarp.Network.connect(base + "/ofeeder/objectsOut", base + "/dmonitor/objectsIn")
+        yarp.Network.connect(base + "/ofeeder/objectOut", base + "/dmonitor/objectsIn")
 
     def close(self):
-        for p in (self.object_port, self.param_port, self.objects_out):
+        for p in (self.object_port, self.param_port, self.objects_out, self.object_f_port):
             p.close()
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -80,6 +82,11 @@ class ObjectFeeder:
             self.handle(b)
 
     def handle(self, b):
+        fb = self.object_f_port.prepare()   # object_feeder:106-110
+        fb.clear()
+        for i in range(b.size()):
+            fb.add(b.get(i))
+        self.object_f_port.writeStrict()
         if b.size() < 2:
             return
         action = b.get(0).toString()
