@@ -188,6 +188,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reps", type=int, default=30, help="repetitions of the timed region (K steps each); value = median repetition")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--secondary", type=int, default=1, help="C3 at N = 1: also time the batch with per-arm (safe distance, force) pairs and with "
+                    "integer orders that differ (never `value`); 0: skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes / threads of the CPU baseline (0 = this box's CPU share, at most 16)")
     ap.add_argument("--rollout", type=int, default=100, help="also time vfik_rollout with this many cycles per launch (0 = skip)")
@@ -281,29 +283,52 @@ def worker(args):
         # launcher rank 0 does)
         store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
         if backend == "nccl":
-            ok, why = 1, ""
+            from vfclik_amd import launcher
+            import datetime
+            bound = float(os.environ.get("VFIK_BENCH_PG_TIMEOUT", "120"))
+            # (1) agree BEFORE anyone enters the collective communicator start (launcher.agree_on_backend): a rank whose local
+            # pre-check fails -- RCCL missing, its device unusable, a device it shares with another rank -- takes everybody to gloo
+            ok, why, dev_id = True, "", ""
             try:
-                if os.environ.get("VFIK_BENCH_FAIL_NCCL") == "1":
-                    raise RuntimeError("VFIK_BENCH_FAIL_NCCL=1 (rehearsal of the fallback)")
-                dist.init_process_group("nccl", store=dist.PrefixStore("nccl", store), rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-                t = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(t)           # the communicator really works
+                forced = os.environ.get("VFIK_BENCH_FAIL_NCCL") == "1" or os.environ.get("VFIK_BENCH_FAIL_NCCL_RANK") == str(rank)
+                if forced:
+                    raise RuntimeError("forced by VFIK_BENCH_FAIL_NCCL%s (rehearsal of the fallback)" % ("" if os.environ.get("VFIK_BENCH_FAIL_NCCL") == "1" else "_RANK"))
+                if not dist.is_nccl_available():
+                    raise RuntimeError("torch.distributed has no nccl (RCCL) backend")
+                torch.zeros(1, device=torch.device("cuda", local_rank)).add_(1)
                 torch.cuda.synchronize()
-                ok = 1 if int(t.item()) == world else 0
-            except Exception as e:  # noqa: BLE001 -- whatever RCCL / c10d raise
-                ok, why = 0, (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
-            store.set("nccl_ok_%d" % rank, str(ok))
-            all_ok = all(store.get("nccl_ok_%d" % r) == b"1" for r in range(world))   # (get blocks until the key exists)
-            if not all_ok:
-                if dist.is_initialized():
+                prop = torch.cuda.get_device_properties(local_rank)
+                dev_id = str(getattr(prop, "uuid", "")) or "%s/%s" % (getattr(prop, "pci_bus_id", local_rank), getattr(prop, "pci_device_id", ""))
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+            backend, why, _ = launcher.agree_on_backend(store, rank, world, (ok, why, dev_id), timeout_s=bound)
+            if backend == "nccl":
+                # (2) every pre-check passed: bring RCCL up eagerly (device_id) and prove it with one all-reduce -- under a watchdog,
+                # because a peer that dies inside ncclCommInitRank would otherwise leave this rank there for good
+                ok = 1
+                with launcher.Watchdog(bound, "rank %d: RCCL communicator start" % rank):
                     try:
-                        dist.destroy_process_group()
-                    except Exception:  # noqa: BLE001
-                        pass
-                backend = "gloo"
+                        dist.init_process_group("nccl", store=dist.PrefixStore("nccl", store), rank=rank, world_size=world,
+                                                device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=bound))
+                        t = torch.ones(1, device=torch.device("cuda", local_rank))
+                        dist.all_reduce(t)           # the communicator really works
+                        torch.cuda.synchronize()
+                        ok = 1 if int(t.item()) == world else 0
+                    except Exception as e:  # noqa: BLE001 -- whatever RCCL / c10d raise
+                        ok, why = 0, (str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+                    store.set("nccl_ok_%d" % rank, str(ok))
+                    all_ok = all(store.get("nccl_ok_%d" % r) == b"1" for r in range(world))   # (bounded: the store's timeout is `bound`)
+                if not all_ok:
+                    if dist.is_initialized():
+                        try:
+                            dist.destroy_process_group()
+                        except Exception:  # noqa: BLE001
+                            pass
+                    backend = "gloo"
+                    why = why or "another rank's communicator did not come up"
+            if backend == "gloo":
                 backend_note = "gloo (RCCL communicator not available on every rank%s): barrier / timing reductions on the CPU" % (": " + why if why else "")
-                print("[bench] rank %d: falling back to gloo for the barrier and the timing reductions%s" % (rank, ": " + why if why else ""), file=sys.stderr)
+                print("[bench] rank %d: gloo for the barrier and the timing reductions%s" % (rank, ": " + why if why else ""), file=sys.stderr)
                 dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
@@ -357,6 +382,16 @@ def worker(args):
             ktrace = json.load(open(kt)).get(args.workload)
         except Exception:
             ktrace = None
+    # what the wave executed (profiles/pmc_sq.json, written by tools/profile_digest.py from the round's SQ counter pass of this command):
+    # the VALU floor beside the HBM figure -- with one wave per SIMD the launch cannot be shorter than its wave's vector instructions
+    # at 4 cycles each (wave64 on a 16-lane SIMD; float64 FMA is full rate on gfx950)
+    sq = None
+    sqf = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    if os.path.exists(sqf):
+        try:
+            sq = json.load(open(sqf)).get(args.workload)
+        except Exception:
+            sq = None
     # rotating input sets (the COLD state): enough of them that the bytes touched between two uses of a set exceed 640 MiB
     per_launch = float(traffic) if traffic else float(bytes_per_cycle * B)
     n_sets = 0
@@ -502,6 +537,43 @@ def worker(args):
                 "real_bytes_frac": (traffic / (cu * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "cycles_per_s": world * B / (cu * 1e-6), "launches_timed": R * K}
 
+    # secondary figures (never `value`): the headline scene is the friendliest one -- every decay repeller with the feeder's safe
+    # distance, force and order (uniform image, 16 B a slot, order 5 straight-line).  The same batch (a) with each arm's own safe
+    # distance and force (compact image, 24 B a slot) and (b) with integer orders that differ by obstacle as in old/README.old:75
+    # (order-20 obstacles beside an order-5 near-goal repeller: the order planes, MIXO kernel variants), warm, HIP events only.
+    secondary = None
+    if world == 1 and args.workload == "C3" and args.secondary:
+        secondary = {}
+        rng2 = np.random.default_rng(77)
+        variants = {}
+        f1 = w["fields"].copy()
+        f1["p"][:, 1:1 + nobs, 4] = rng2.uniform(0.001, 0.004, (B, 1)).astype(io_dtype)
+        f1["force"][:, 1:1 + nobs] = rng2.uniform(-12.0, -8.0, (B, 1)).astype(io_dtype)
+        variants["per_arm_safe_distance_and_force"] = f1
+        f2 = w["fields"].copy()
+        f2["p"][:, 1:1 + nobs, 5] = [5.0] + [20.0] * (nobs - 1)
+        variants["orders_5_and_20_by_obstacle"] = f2
+        f3 = w["fields"].copy()
+        f3["p"][:, 1:1 + nobs, 5] = rng2.integers(1, 21, (B, nobs)).astype(np.float64)
+        variants["orders_of_each_arm_its_own"] = f3
+        from oracle import oracle_c as _oc   # checker only
+        for name, fv in variants.items():
+            e2 = engine.Engine(chain, B, io_dtype=io_dtype.type, max_slots=nobs, device=local_rank, params=params)
+            e2.set_fields(fv, w["nfields"])
+            e2.use_stream(stream.cuda_stream)
+            o2 = torch.zeros(B, chain.n, dtype=tdt, device=dev)
+            io2 = e2.make_io(q, qdot_out=o2)
+            for _ in range(max(3, args.warmup)):
+                e2.step(io2)
+            torch.cuda.synchronize()
+            _, _, ms2 = timed([(e2, io2)], K, min(R, 10), wall=False)
+            us2 = pctl([m * 1e3 / K for m in ms2], 50)
+            ref2 = _oc.cycle_batch(chain, params, w["q"][:4096], fv[:4096], w["nfields"][:4096], want=("qdot_out",))
+            secondary[name] = {"us_per_launch": us2, "cycles_per_s": B / (us2 * 1e-6), "frac": bytes_per_cycle * B / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                               "field_path": e2.field_path, "uniform_repellers": e2.uniform_repellers, "mixed_orders": e2.mixed_orders,
+                               "max_abs_err_rad_s_first_4096_arms": float(np.abs(o2[:4096].cpu().numpy().astype(np.float64) - ref2["qdot_out"]).max())}
+            e2.close()
+
     # secondary figure (never `value`): closed-loop rollout, K control cycles per launch with q integrated in
     # registers -- what the cycle costs once the per-launch boundary is amortised
     rollout = None
@@ -616,6 +688,19 @@ def worker(args):
         }
         if args.sync_each:
             line["diagnostic"] = "--sync-each: every launch was followed by a synchronize; not a throughput measurement"
+        if sq and sq.get("SQ_INSTS_VALU"):
+            clock = float(sq.get("clock_ghz", 2.2))
+            floor_us = sq["SQ_INSTS_VALU"] * 4.0 / (clock * 1e3)
+            line["roofline"]["valu"] = {
+                "insts_per_wave": sq["SQ_INSTS_VALU"], "floor_us": floor_us, "frac": floor_us / us_med, "clock_ghz": clock,
+                "salu_per_wave": sq.get("SQ_INSTS_SALU"), "active_quad_cycles_per_wave": sq.get("SQ_ACTIVE_INST_ANY"),
+                "issue_stall_quad_cycles_per_wave": sq.get("SQ_WAIT_INST_ANY"),
+                "meaning": "the launch's waves are one per SIMD: floor_us = VALU instructions of a wave x 4 cycles / clock is the time the SIMD "
+                           "needs to issue them if nothing ever stalled; frac = floor_us / launch period.  This, not HBM, is the roof that binds "
+                           "(DESIGN.md 5.3): the kernel computes in float64, one instruction per 4 cycles per SIMD",
+                "source": "profiles/pmc_sq.json (rocprofv3 --pmc SQ_* pass of this command, round %s; not measured by this run)" % sq.get("round")}
+        if secondary is not None:
+            line["secondary"] = secondary
         if cold is not None:
             line["roofline"]["cold"] = cold
         if ktrace:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VFIK_ABI_VERSION 4
+#define VFIK_ABI_VERSION 5
 
 enum {
     VFIK_OK = 0,
@@ -266,16 +266,23 @@ long vfik_small_batch_launches(vfik_handle* h);
 /* introspection for tests / DESIGN.md: slots in use, bytes of device state */
 int vfik_slots_in_use(vfik_handle* h);
 /* Which field path the handle's current field sets select for a cycle launch (decided when they are packed, vfik_set_fields):
- * 1 = straight-line: every arm is goal + decay repellers of one integer order (what object_feeder sends for point obstacles,
- * object_feeder:317-334); 2 = straight-line with an aux block: as 1, and arms may carry ONE funnel attractor and ONE hemisphere
+ * 1 = straight-line: every arm is goal + decay repellers with integer orders (what object_feeder sends for point obstacles,
+ * object_feeder:317-334: order 5 throughout; since ABI 5 the orders may differ between obstacles and between arms, as in
+ * old/README.old:75, `ObstacleP ... 0.05 20`, beside the feeder's own order-5 near-goal repeller -- vfik_mixed_orders); 2 = straight-line with an aux block: as 1, and arms may carry ONE funnel attractor and ONE hemisphere
  * repeller with integer decay orders -- the goalAndNormal scene (object_feeder:248-303: attractor + approach funnel + near-goal
  * repeller + obstacles) and a surface (ObstacleH, object_feeder:344-353);
- * 0 = general: anything else (further attractors, several funnels or hemispheres, fractional or mixed orders), entry by entry. */
+ * 0 = general: anything else (further attractors, several funnels or hemispheres, fractional orders or orders >= 128), entry by entry. */
 int vfik_field_path(vfik_handle* h);
 /* 1 when every decay repeller of the batch carries the same safe distance and the same force -- what the object feeder sends
  * (0.001 and -10 for every point obstacle and for the near-goal repeller: object_feeder:301-302,323,331): on field path 1 the lean
  * launches then read one quad (x y z radius) per repeller instead of 24 bytes, the pair from the batch constants.  0 otherwise. */
 int vfik_uniform_repellers(vfik_handle* h);
+/* ABI 5.  1 when the decay repellers of the batch have integer orders that are not all the same: lean and publishing-lean
+ * single-cycle launches of chains without a tool / weights then read one order byte per repeller beside the compact image and stay
+ * on field path 1 / 2 (a wave whose 64 arms agree slot by slot pays scalar control flow only; a wave with an odd arm per-lane
+ * selects); every other launch of such a batch (rollouts, per-arm options) takes the general path.  0 otherwise -- also with the
+ * environment variable VFIK_MIXED_ORDERS=0, which restores the behaviour of ABI 4 (differing orders -> field path 0). */
+int vfik_mixed_orders(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);
 
 #ifdef __cplusplus

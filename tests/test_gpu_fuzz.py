@@ -28,6 +28,11 @@ def _random_fields(abi, chain, B, rng, dt, general):
     F = np.zeros((B, M), dtype=abi.FIELD_DTYPE)
     n = np.zeros(B, dtype=np.int32)
     order = float(rng.choice([2.0, 5.0, 20.0]))
+    # a third of the repeller-only configurations: integer orders that differ by field (round 4: the order planes / MIXO variants);
+    # a few of those with orders that differ by arm as well
+    by_field = (not general) and rng.random() < 0.33
+    by_arm = by_field and rng.random() < 0.4
+    table = rng.choice([0.0, 1.0, 2.0, 3.0, 5.0, 20.0, 31.0], size=M)
     for b in range(B):
         cnt = int(rng.integers(0, M + 1))
         for k in range(cnt):
@@ -43,7 +48,8 @@ def _random_fields(abi, chain, B, rng, dt, general):
                 f["force"] = float(rng.choice([-10.0, -4.0])) if mixed else -10.0
                 f["p"][:6] = [*rng.uniform(-0.8, 0.8, 2), rng.uniform(0, 1.2), rng.uniform(0.03, 0.1),
                               float(rng.choice([0.001, 0.004])) if mixed else 0.001,
-                              order if not general else float(rng.choice([2.0, 5.0, 3.5]))]
+                              (float(rng.integers(0, 12)) if by_arm and rng.random() < 0.2 else float(table[k]) if by_field else order)
+                              if not general else float(rng.choice([2.0, 5.0, 3.5]))]
             elif t == 4:
                 f["force"] = -50.0
                 f["p"][:8] = [*rng.uniform(-0.5, 0.5, 2), -0.5, *(rng.normal(size=2) * 0.1), 1.0, 0.05, 5.0]

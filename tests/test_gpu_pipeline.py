@@ -180,3 +180,43 @@ def test_bench_two_ranks_fall_back_to_gloo_when_rccl_cannot_start():
     assert line["n_gpus"] == 2 and line["value"] > 1e9
     assert line["config"]["process_group"].startswith("gloo (RCCL communicator not available"), line["config"]["process_group"]
     assert line["max_abs_err_rad_s"] < 1e-6
+
+
+def test_sharded_engine_runs_its_handles_concurrently():
+    """ShardedEngine.step_host submits the cycle to every handle before it waits for the first (vfclik:88-105: the per-arm process
+    sets of the reference run side by side).  On the one GPU of this box: two handles of 4 096 arms on device 0 through
+    ShardedEngine(devices=[0, 0]) against ONE such handle -- run one after the other they would take 2 x; the bar is 1.7 x."""
+    import time
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots, sharding, synth
+    chain = robots.lwr()
+    B = 4096
+    params = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+    w = synth.make_workload(chain, 2 * B, 4, seed=3, io_dtype=np.float32)
+    one = sharding.ShardedEngine(chain, B, rank=0, world=1, devices=[0], io_dtype=np.float32, max_slots=4, params=params)
+    two = sharding.ShardedEngine(chain, 2 * B, rank=0, world=1, devices=[0, 0], io_dtype=np.float32, max_slots=4, params=params)
+    one.set_fields(w["fields"][:B], w["nfields"][:B])
+    two.set_fields(w["fields"], w["nfields"])
+    q1, q2 = w["q"][:B].astype(np.float32), w["q"].astype(np.float32)
+    want = ("qdot_out", "status")
+    o1 = one.step_host(q1, want=want)
+    o2 = two.step_host(q2, want=want)
+
+    def rate(sh, q, into):
+        best = 1e9
+        for _ in range(7):
+            t0 = time.perf_counter()
+            for _ in range(100):
+                sh.step_host(q, want=want, into=into)
+            best = min(best, (time.perf_counter() - t0) / 100)
+        return best
+
+    t1, t2 = rate(one, q1, o1), rate(two, q2, o2)
+    print("one handle of %d arms: %.1f us per cycle; two handles through ShardedEngine(devices=[0, 0]): %.1f us (%.2f x)" % (B, t1 * 1e6, t2 * 1e6, t2 / t1))
+    ref = oracle_c.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], want=("qdot_out",))
+    assert np.abs(o2["qdot_out"] - ref["qdot_out"]).max() < 1e-6 and np.array_equal(o2["qdot_out"][:B], o1["qdot_out"])
+    assert t2 < 1.7 * t1, (t1, t2)
+    one.close()
+    two.close()

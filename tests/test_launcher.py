@@ -202,3 +202,77 @@ def test_rank_cpus_near_the_gpu_numa_node():
     assert launcher.rank_cpus_near_gpu(1, 2, cpus, None if launcher.gpu_local_cpus() is None else [node0], groups=smt) == launcher.rank_cpus(1, 2, cpus, groups=smt)
     assert launcher.rank_cpus_near_gpu(0, 2, cpus, [set(), set()], groups=smt) == launcher.rank_cpus(0, 2, cpus, groups=smt)
     assert launcher._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
+# ---- which backend carries the barrier: agreed through the store BEFORE the collective communicator start ----
+def test_decide_backend_rules():
+    from vfclik_amd import launcher
+    ok = (True, "", "GPU-a")
+    assert launcher.decide_backend([ok, (True, "", "GPU-b")]) == ("nccl", "")
+    b, why = launcher.decide_backend([ok, (False, "no RCCL", "")])
+    assert b == "gloo" and why.startswith("rank 1: no RCCL")
+    b, why = launcher.decide_backend([ok, (True, "", "GPU-b"), (True, "", "GPU-a")])
+    assert b == "gloo" and "ranks 0 and 2 share device GPU-a" in why
+    assert launcher.decide_backend([(True, "", ""), (True, "", "")])[0] == "nccl"   # unknown device ids: RCCL is tried (under the watchdog)
+
+
+AGREE_SCRIPT = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from vfclik_amd import launcher
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    mode = sys.argv[1]
+    store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
+    t0 = time.time()
+    if mode == "one_fails":          # ONLY rank 1 fails its pre-check: every rank must still reach gloo, nobody enters a collective first
+        pre = (rank != 1, "device lost" if rank == 1 else "", "GPU-%%d" %% rank)
+    elif mode == "shared":
+        pre = (True, "", "GPU-0")
+    elif mode == "silent":           # rank 1 never publishes: rank 0 must give up after the bound, not hang
+        if rank == 1:
+            time.sleep(30)
+            sys.exit(0)
+        pre = (True, "", "GPU-0")
+    else:
+        pre = (True, "", "GPU-%%d" %% rank)
+    backend, why, got = launcher.agree_on_backend(store, rank, world, pre, timeout_s=3.0)
+    if backend == "gloo":
+        dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"backend": backend, "why": why, "seconds": time.time() - t0}))
+""") % ROOT
+
+
+@pytest.mark.parametrize("mode,backend,why", [("one_fails", "gloo", "rank 1: device lost"), ("shared", "gloo", "share device GPU-0"), ("fine", "nccl", "")])
+def test_ranks_agree_on_the_backend_through_the_store(tmp_path, mode, backend, why):
+    from vfclik_amd import launcher
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_SCRIPT)
+    rc, out = launcher.spawn_ranks([sys.executable, str(script), mode], 2, timeout=120)
+    assert rc == 0, out
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["backend"] == backend and why in line["why"] and line["seconds"] < 30
+
+
+def test_a_rank_that_never_publishes_costs_a_bounded_wait(tmp_path):
+    from vfclik_amd import launcher
+    import time
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_SCRIPT)
+    t0 = time.time()
+    rc, out = launcher.spawn_ranks([sys.executable, str(script), "silent"], 2, timeout=120)
+    assert rc != 0 and time.time() - t0 < 25     # rank 0 raised after its 3-s bound; the parent ended rank 1
+
+
+def test_watchdog_ends_a_process_that_is_stuck(tmp_path):
+    import subprocess
+    import time
+    code = "import sys, time; sys.path.insert(0, %r)\nfrom vfclik_amd import launcher\nwith launcher.Watchdog(0.5, 'test', code=7):\n    time.sleep(30)\n" % ROOT
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 7 and time.time() - t0 < 20 and "did not finish within" in p.stderr
+    code = "import sys; sys.path.insert(0, %r)\nfrom vfclik_amd import launcher\nwith launcher.Watchdog(5, 'test', code=7):\n    pass\nprint('ok')\n" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "ok"

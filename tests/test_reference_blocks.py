@@ -243,3 +243,30 @@ def test_object_feeder_bottle_sequences_equal_the_reference_record(golden_dir):
         assert log == exp, name
         assert sorted(feeder.objects) == sc["objects_left"], name
         feeder.close()
+
+
+def test_batched_tracking_state_equals_the_reference_record_and_the_per_arm_class(golden_dir):
+    """TrackingStateBatch (what ControlCycleBatch runs for thousands of arms) gives, arm by arm, the messages of TrackingState --
+    and so those of the reference's block -- also when arms are fed at different times."""
+    from vfclik_amd.vf_module import TrackingStateBatch
+    doc = json.load(open(os.path.join(golden_dir, "tracking_state_golden.json")))
+    S = np.array(doc["samples"])
+    B = 5
+    tb = TrackingStateBatch(B)
+    single = [TrackingState() for _ in range(B)]
+    rng = np.random.default_rng(0)
+    fed = np.zeros(B, dtype=int)            # arm b replays the record from its own position, at its own pace
+    got = {b: [] for b in range(B)}
+    exp = {b: [] for b in range(B)}
+    while fed[0] < len(S):
+        arms = np.array([b for b in range(B) if (b == 0 or rng.random() < 0.6) and fed[b] < len(S)])
+        rows = S[fed[arms]]
+        for a, kind, state in tb.update(arms, rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]):
+            got[a].append([int(fed[a]), kind, state])
+        for j, b in enumerate(arms):
+            for kind, state in single[b].update(*rows[j]):
+                exp[b].append([int(fed[b]), kind, state])
+        fed[arms] += 1
+    assert got[0] == doc["messages"]
+    for b in range(B):
+        assert got[b] == exp[b] and (b == 0 or len(got[b]) >= 4)

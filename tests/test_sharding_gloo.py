@@ -89,10 +89,18 @@ class _OracleEngine:
         assert fields.shape[0] == self.batch and counts.shape[0] == self.batch
         self.fields, self.counts = fields, counts
 
-    def step_host(self, q, null_control=None, want=("qdot_out",), **kw):
+    io_dtype = np.float64
+
+    def step_host(self, q, null_control=None, want=("qdot_out",), into=None, active=None, **kw):
         from oracle import oracle_c
         assert q.shape[0] == self.batch
-        return oracle_c.cycle_batch(self.chain, self.params, q, self.fields, self.counts, null_control=null_control, want=tuple(want))
+        out = oracle_c.cycle_batch(self.chain, self.params, q, self.fields, self.counts, null_control=null_control, want=tuple(want),
+                                   active=active, into=None if into is None else {k: v.copy() for k, v in into.items()})
+        if into is not None:
+            for k in want:
+                into[k][...] = out[k]
+            return into
+        return out
 
     def close(self):
         pass
@@ -162,3 +170,74 @@ def test_sharded_engine_single_process_over_several_devices():
     with pytest.raises(ValueError):
         sh.step_host(w["q"][:5])
     sh.close()
+
+
+class _PipelinedEngine(_OracleEngine):
+    """... with the pipelined host path (submit_host / wait) and a log of the calls."""
+    log = []
+
+    def host_array(self, shape, dtype=None):
+        return np.zeros(shape, dtype=np.float64 if dtype is None else dtype)
+
+    def submit_host(self, q, outs, null_control=None, q_ref=None, q_cmded=None, active=None, q_lo=None, q_hi=None):
+        _PipelinedEngine.log.append(("submit", self.device))
+        self._pending = (q.copy(), outs, null_control, active)
+        return 17 + self.device
+
+    def wait(self, ticket):
+        from oracle import oracle_c
+        assert ticket == 17 + self.device
+        _PipelinedEngine.log.append(("wait", self.device))
+        q, outs, nc, active = self._pending
+        res = oracle_c.cycle_batch(self.chain, self.params, q, self.fields, self.counts, null_control=nc, want=tuple(outs), active=active,
+                                   into={k: v.copy() for k, v in outs.items()})
+        for k in outs:
+            outs[k][...] = res[k]
+
+
+def test_every_device_gets_its_work_before_the_first_wait():
+    """ShardedEngine.step_host in one process over several devices: all submits precede the first wait (the devices run
+    concurrently, as the reference's per-arm process sets do, vfclik:88-105); results equal the un-sharded computation; `into`
+    is honoured; the gated form (no pipelined path) goes through one thread per device and gives the same rows."""
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots, sharding, synth
+    oracle_c.build()
+    chain = robots.lwr()
+    w = synth.make_workload(chain, 41, 2, seed=9, io_dtype=np.float64)
+    ref = oracle_c.cycle_batch(chain, _abi.default_params(), w["q"], w["fields"], w["nfields"], want=("qdot_out", "pose", "status"))
+    _PipelinedEngine.log = []
+    sh = sharding.ShardedEngine(chain, 41, rank=0, world=1, devices=[0, 1, 2], engine_factory=_PipelinedEngine)
+    sh.set_fields(w["fields"], w["nfields"])
+    out = sh.step_host(w["q"], want=("qdot_out", "pose", "status"))
+    kinds = [k for k, _ in _PipelinedEngine.log]
+    assert kinds == ["submit"] * 3 + ["wait"] * 3, _PipelinedEngine.log
+    for k in ("qdot_out", "pose", "status"):
+        assert np.array_equal(out[k], ref[k])
+    # into: the same arrays come back, written in place
+    again = sh.step_host(w["q"], want=("qdot_out", "pose", "status"), into=out)
+    assert again["qdot_out"] is out["qdot_out"] and np.array_equal(out["qdot_out"], ref["qdot_out"])
+    # the fresh-q gate travels the same way; gated arms keep their rows of `into`
+    _PipelinedEngine.log = []
+    gate = np.arange(41) % 3 != 0
+    marked = {"qdot_out": np.full((41, 7), 9.0)}
+    got = sh.step_host(w["q"], want=("qdot_out",), active=gate, into=marked)
+    assert [k for k, _ in _PipelinedEngine.log] == ["submit"] * 3 + ["wait"] * 3
+    assert np.array_equal(got["qdot_out"][gate], ref["qdot_out"][gate]) and np.all(got["qdot_out"][~gate] == 9.0)
+    sh.close()
+    # handles without the pipelined path: one thread per device around step_host, same rows
+    sh = sharding.ShardedEngine(chain, 41, rank=0, world=1, devices=[0, 1, 2], engine_factory=_OracleEngine)
+    sh.set_fields(w["fields"], w["nfields"])
+    marked = {"qdot_out": np.full((41, 7), 9.0)}
+    got = sh.step_host(w["q"], want=("qdot_out",), active=gate, into=marked)
+    assert np.array_equal(got["qdot_out"][gate], ref["qdot_out"][gate]) and np.all(got["qdot_out"][~gate] == 9.0)
+    sh.close()
+
+
+def test_a_rank_without_arms_returns_empty_rows():
+    """More ranks than arms: the rank owns no part; its step returns (0, columns) arrays instead of raising."""
+    from vfclik_amd import robots, sharding
+    chain = robots.lwr()
+    sh = sharding.ShardedEngine(chain, 2, rank=3, world=4, devices=[0], engine_factory=_OracleEngine)
+    assert sh.local_rows == 0 and not sh.parts
+    out = sh.step_host(np.zeros((0, 7)), want=("qdot_out", "pose", "status"), global_rows=False)
+    assert out["qdot_out"].shape == (0, 7) and out["pose"].shape == (0, 16) and out["status"].shape == (0,)

@@ -17,7 +17,7 @@ def run(setting, workload, state):
         k, v = setting.split("=", 1)
         env[k] = v
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--no-cpu-baseline", "--host-path", "0",
-                          "--rollout", "0", "--steps", "200", "--reps", "30", "--state", state, "--launch", "direct"], env=env, capture_output=True, text=True, timeout=600)
+                          "--rollout", "0", "--steps", "200", "--reps", "30", "--state", state, "--launch", "direct", "--secondary", "0"], env=env, capture_output=True, text=True, timeout=600)
     d = json.loads(out.stdout.strip().split("\n")[-1])
     return d["roofline"]["us_per_launch_p10"]
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Rates of the DROP-IN path: ControlCycleBatch.cycle() -- per-arm port polling in Python, one fused call (cycle kernel +
-tracking-error estimator + distance monitor on the device, one synchronisation), per-arm publishing -- against the array path
-(step_arrays / Engine.step_host: no bottle anywhere) at B = 1, 64, 4 096 arms.  cycles/s = arm-cycles per second."""
+"""Rates of the DROP-IN path: ControlCycleBatch.cycle() -- mail-driven port polling, one fused call (cycle kernel +
+tracking-error estimator + distance monitor on the device, one synchronisation), publishing to the ports somebody reads --
+against the array path (step_arrays / Engine.step_host: no bottle anywhere) at B = 1, 64, 4 096 arms.  Every arm has a goal
+and a monitored object and gets fresh joint angles every cycle: (a) as ONE (B, n) array (write_encoders), nobody listening to
+the outputs; (b) the same with a reader on every arm's /qdotOut and /pose (two bottles per arm and cycle are really read);
+(c) as B bottles on /bridge/encoders, the reference's way.  cycles/s = arm-cycles per second."""
 import os
 import sys
 import time
@@ -22,7 +25,7 @@ def bottle(values):
 
 
 chain = robots.lwr()
-print("%6s %28s %28s %28s" % ("arms", "cycle() with ports", "step_arrays, all outputs", "step_arrays, qdot_out only"))
+print("%6s %26s %26s %26s %26s %26s" % ("arms", "cycle(), (a) array in", "(b) + 2 readers per arm", "(c) per-arm bottles in", "step_arrays, all outputs", "step_arrays, qdot_out"))
 for B in (1, 64, 4096):
     bases = ["/%d/lwr/right" % i for i in range(B)]
     cb = ControlCycleBatch(chain, bases, io_dtype=np.float64, max_fields=8)
@@ -57,13 +60,31 @@ for B in (1, 64, 4096):
                 b.addDouble(float(v))
             enc[a].write()
 
-    feed(); cb.cycle()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        feed()
-        got = cb.cycle()
-    t_ports = (time.perf_counter() - t0) / n
-    assert got.all()
+    def timed(feeder, reps):
+        feeder(); cb.cycle()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            feeder()
+            got = cb.cycle()
+        assert got.all()
+        return (time.perf_counter() - t0) / reps
+
+    t_array = timed(lambda: cb.write_encoders(q), n)
+    readers = []
+    for base in bases:       # somebody reads two of every arm's outputs
+        for name in ("/vectorField/qdotOut", "/vectorField/pose"):
+            r = yarp.BufferedPortBottle()
+            r.open(base + "/test/reader" + name)
+            yarp.Network.connect(base + name, base + "/test/reader" + name)
+            readers.append(r)
+
+    def feed_and_read():
+        cb.write_encoders(q)
+    t_read = timed(feed_and_read, n)
+    for r in readers:
+        assert r.read(False).size() in (7, 16)
+        r.close()
+    t_ports = timed(feed, max(3, n // 4))
     full = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status", "goal_dist", "track_error", "obj_dist")
     n2 = 300
     cb.step_arrays(q, want=full)
@@ -75,5 +96,5 @@ for B in (1, 64, 4096):
     for _ in range(n2):
         cb.step_arrays(q)
     t_lean = (time.perf_counter() - t0) / n2
-    print("%6d %14.1f us %9.3g c/s %14.1f us %9.3g c/s %14.1f us %9.3g c/s" % (B, t_ports * 1e6, B / t_ports, t_full * 1e6, B / t_full, t_lean * 1e6, B / t_lean), flush=True)
+    print("%6d" % B + "".join(" %12.1f us %9.3g c/s" % (t * 1e6, B / t) for t in (t_array, t_read, t_ports, t_full, t_lean)), flush=True)
     cb.close()

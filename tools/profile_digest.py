@@ -107,18 +107,30 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     print()
+    sqj = {}
     for w in ("C2", "C2F", "C3", "C3N", "C5", "C3F", "C5F"):
         f = one(os.path.join(d, "pmc_sq_" + w, "*", "*counter_collection.csv"))
         if not f:
             continue
         per = {}
+        kname = None
         for r in csv.DictReader(open(f)):
             if "::cycle_" not in r["Kernel_Name"]:
                 continue
+            kname = r["Kernel_Name"]
             per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        if not per:
+            continue
         print("%s per wave (%d waves), median over %d dispatches: " % (w, WAVES[w], len(next(iter(per.values())))) +
               ", ".join("%s %.0f" % (k, statistics.median(v.values()) / WAVES[w]) for k, v in sorted(per.items())))
+        # per wave: what bench.py's roofline.valu quotes (in-kernel clock 2.15-2.2 GHz by the s_memtime stamps of tools/stamps.py)
+        sqj[w] = {k: statistics.median(v.values()) / WAVES[w] for k, v in sorted(per.items())}
+        sqj[w].update({"waves": WAVES[w], "round": rnd, "kernel": kernel_of(kname), "clock_ghz": 2.2,
+                       "dispatches_sampled": len(next(iter(per.values())))})
+    if sqj:
+        with open(os.path.join(ROOT, "profiles", "pmc_sq.json"), "w") as f:
+            json.dump(sqj, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 4  # include/vfik.h: VFIK_ABI_VERSION
+ABI_VERSION = 5  # include/vfik.h: VFIK_ABI_VERSION
 MAX_JOINTS = 16
 MAX_PARAMS = 17
 MIX_CHANNELS = 6

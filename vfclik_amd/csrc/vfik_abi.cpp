@@ -83,9 +83,12 @@ struct vfik_handle {
     std::vector<char> arm_pair_state;     // per arm: 0 no decay repeller, 1 all of them share one (safe, force), 2 mixed
     std::vector<double> arm_safe, arm_force;
     int uni_allowed = 1;                  // VFIK_UNIFORM_IMAGE=0: always the compact image (tests, A/B)
+    int mixed_allowed = 1;                // VFIK_MIXED_ORDERS=0: differing integer orders take the general path, as until round 3 (tests, A/B)
     int uni_ok = 0;                       // the batch's decay repellers share one pair, now in the device constants (KConst::rep_safe, dh[0].pad)
     double uni_safe = 0.0, uni_force = 0.0;
     void* d_slots_fast = nullptr;  // compact repeller image for the straight-line path: 3 quad planes per PAIR of slots
+    void* d_orders = nullptr;      // order planes: 16 bytes per arm and plane, one byte per compact-image slot (vfik_kernel.h); read when `mixed`
+    int mixed = 0;                 // the batch's decay repellers have integer orders that differ (between slots or between arms)
     void* d_tool = nullptr;    // 3 quad planes (per-arm tools only)
     double tool_shared[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     int tool_per_arm = 0;
@@ -176,7 +179,8 @@ template <typename T>
 void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts, int n_arms, int S,
                  std::vector<char>& goal, std::vector<char>& slots, std::vector<char>& fast, std::vector<int>& used,
                  std::vector<char>& funnel, std::vector<int>& used_fast, std::vector<char>& has_funnel,
-                 std::vector<char>& uni, std::vector<char>& pair_state, std::vector<double>& pair_safe, std::vector<double>& pair_force) {
+                 std::vector<char>& uni, std::vector<char>& pair_state, std::vector<double>& pair_safe, std::vector<double>& pair_force,
+                 std::vector<unsigned char>& ord) {
     funnel.assign((size_t)6 * n_arms * 4 * sizeof(T), 0);  // aux block: funnel planes 0..2, hemisphere planes 3..5
     goal.assign((size_t)4 * n_arms * 4 * sizeof(T), 0);
     slots.assign((size_t)std::max(1, 2 * S) * n_arms * 4 * sizeof(T), 0);
@@ -189,6 +193,9 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
     uni.assign((size_t)std::max(1, S) * n_arms * 4 * sizeof(T), 0);
     // (the force being the batch's, a slot an arm does not use cannot carry force 0 as in the other images: its radius is -inf)
     for (size_t q4 = 0; q4 < (size_t)std::max(1, S) * n_arms; ++q4) put<T>(uni, q4 * 4 + 3, -std::numeric_limits<double>::infinity());
+    // order planes: byte (m % 16) of plane (m / 16) = the integer decay order of compact-image slot m; slots an arm does not use
+    // repeat the order of its last repeller (5 -- what the feeder sends, object_feeder:302,333 -- for an arm without any)
+    ord.assign((size_t)((std::max(1, S) + 15) / 16) * n_arms * 16, 5);
     std::vector<int> order;
     for (int j = 0; j < n_arms; ++j) {
         const vfik_field* f = fields + (size_t)j * max_fields;
@@ -233,6 +240,10 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
                 const double sv = (double)static_cast<T>(fd.p[4]), fv = (double)static_cast<T>(fd.force);
                 if (pair_state[j] == 0) { pair_state[j] = 1; pair_safe[j] = sv; pair_force[j] = fv; }
                 else if (pair_safe[j] != sv || pair_force[j] != fv) pair_state[j] = 2;
+                {   // (non-integer or large orders send the batch to the general path: the byte is not read then)
+                    const double o = fd.p[5];
+                    ord[((size_t)(mr >> 4) * n_arms + j) * 16 + (mr & 15)] = (o >= 0.0 && o < 128.0 && (double)(int)o == o) ? (unsigned char)(int)o : 0;
+                }
                 const int pair = mr >> 1, half = mr & 1;
                 ++mr;
                 for (int i = 0; i < 6; ++i) {
@@ -248,6 +259,11 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
                 put<T>(slots, at(c, 7), -1.0);
             }
             m += ns;
+        }
+        if (mr > 0) {   // the slots behind the last repeller repeat ITS order: a partly filled chunk adds no distinct order of its own
+            const size_t np = ord.size() / ((size_t)n_arms * 16);
+            const unsigned char last = ord[((size_t)((mr - 1) >> 4) * n_arms + j) * 16 + ((mr - 1) & 15)];
+            for (size_t ms = mr; ms < np * 16; ++ms) ord[((ms >> 4) * n_arms + j) * 16 + (ms & 15)] = last;
         }
         used[j] = m;
         used_fast[j] = mr;
@@ -303,6 +319,8 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.uni_planes = 3 * ((std::max(1, h->max_slots) + 1) / 2);
     a.stamps = h->d_stamps;
     a.kc = h->d_kconst;
+    a.orders = h->d_orders;
+    a.mixed = h->mixed;
 }
 
 // rewrite the device copy of the batch constants (chain + parameters); rare, synchronous
@@ -322,9 +340,10 @@ int upload_kconst(vfik_handle* h) {
 }
 
 // which arms qualify for the kernel's straight-line repeller path
+// (-1: no repeller; n >= 0: every repeller has integer order n; -3: integer orders that differ; -2: the general path)
 int classify_arm(const vfik_field* f, int count) {
     int order = -1;
-    bool goal = false, funnel = false, hemi = false;
+    bool goal = false, funnel = false, hemi = false, mixed = false;
     for (int k = 0; k < count; ++k) {
         const vfik_field& fd = f[k];
         if (fd.type == VFIK_FIELD_NULL) continue;
@@ -347,10 +366,10 @@ int classify_arm(const vfik_field* f, int count) {
         const double o = fd.p[5];
         const int n = (int)o;
         if (!((double)n == o) || n < 0 || n >= 128) return -2;
-        if (order >= 0 && n != order) return -2;
+        if (order >= 0 && n != order) mixed = true;
         order = n;
     }
-    return order;
+    return mixed ? -3 : order;
 }
 
 int check_handle(const vfik_handle* h) {
@@ -401,6 +420,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (const char* e = std::getenv("VFIK_PERSISTENT")) h->pers = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_TWO_WAVES")) h->waves2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_UNIFORM_IMAGE")) h->uni_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VFIK_MIXED_ORDERS")) h->mixed_allowed = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_ZERO_COPY_MAX")) h->zero_copy_max = (size_t)std::max(0L, std::atol(e));
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
@@ -419,7 +439,8 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
         const size_t sz_su = std::max<size_t>(1, (size_t)max_slots) * quad_plane;      // uniform image: one quad plane per slot
         const size_t sz_sl = std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane;  // >= 1 slot: the prefetch reads slot 0
-        if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_su + sz_sl, true)) return bail("alloc state arena");
+        const size_t sz_or = (std::max<size_t>(1, (size_t)max_slots) + 15) / 16 * (size_t)h->Bpad * 16;   // order planes (zeros: order 0, force 0)
+        if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_su + sz_sl + sz_or, true)) return bail("alloc state arena");
         char* a0 = static_cast<char*>(h->d_arena);
         h->d_goal = a0;
         h->d_funnel = a0 + 4 * quad_plane;
@@ -428,6 +449,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         h->d_slots_fast = a0 + sz_goal + sz_kc + sz_lv;
         h->d_slots_uni = a0 + sz_goal + sz_kc + sz_lv + sz_sf;   // (kernel side: slots_fast + uni_planes quad planes)
         h->d_slots = a0 + sz_goal + sz_kc + sz_lv + sz_sf + sz_su;
+        h->d_orders = a0 + sz_goal + sz_kc + sz_lv + sz_sf + sz_su + sz_sl;
     }
     {   // the uniform image starts out with every slot unused (radius -inf), like the zeros (force 0) of the other two images
         std::vector<char> plane((size_t)h->Bpad * 4 * h->esz, 0);
@@ -658,9 +680,10 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     std::vector<char> goal, slots, fast, funnel, hasf(n_arms), uni, pstate(n_arms);
     std::vector<double> psafe(n_arms), pforce(n_arms);
     std::vector<int> used(n_arms), used_fast(n_arms);
+    std::vector<unsigned char> ord;
     const int S = h->max_slots;
-    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce);
-    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce);
+    if (h->io_dtype == 32) pack_fields<float>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce, ord);
+    else pack_fields<double>(fields, max_fields, counts, n_arms, S, goal, slots, fast, used, funnel, used_fast, hasf, uni, pstate, psafe, pforce, ord);
     const size_t qb = 4 * h->esz, w = (size_t)n_arms * qb, pitch = (size_t)h->Bpad * qb;
     char* dg = static_cast<char*>(h->d_goal) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dg, pitch, goal.data(), w, w, 3, hipMemcpyHostToDevice, h->stream));
@@ -674,6 +697,8 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         HIP_TRY(hipMemcpy2DAsync(df, pitch, fast.data(), w, w, (size_t)((S + 1) / 2) * 3, hipMemcpyHostToDevice, h->stream));
         char* du = static_cast<char*>(h->d_slots_uni) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(du, pitch, uni.data(), w, w, (size_t)S, hipMemcpyHostToDevice, h->stream));
+        char* dor = static_cast<char*>(h->d_orders) + (size_t)first_arm * 16;
+        HIP_TRY(hipMemcpy2DAsync(dor, (size_t)h->Bpad * 16, ord.data(), (size_t)n_arms * 16, (size_t)n_arms * 16, (size_t)(S + 15) / 16, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int j = 0; j < n_arms; ++j) {
@@ -689,12 +714,17 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     h->slots_used_fast = *std::max_element(h->fast_slots_per_arm.begin(), h->fast_slots_per_arm.end());
     h->any_funnel = 0;
     for (char f : h->arm_has_funnel) h->any_funnel |= f;
+    // One integer order for every decay repeller of the batch: the straight-line path with that order as a launch constant.  Integer
+    // orders that differ -- within an arm (-3) or between arms: the straight-line path still, reading the order planes (`mixed`).
     int fo = -1;
-    bool general = false;
+    bool general = false, mixed = false;
     for (int o : h->arm_order) {
-        if (o == -2 || (o >= 0 && fo >= 0 && o != fo)) { general = true; break; }
+        if (o == -2) { general = true; break; }
+        if (o == -3 || (o >= 0 && fo >= 0 && o != fo)) mixed = true;
         if (o >= 0) fo = o;
     }
+    if (!h->mixed_allowed && mixed) general = true;
+    h->mixed = (!general && mixed) ? 1 : 0;
     h->fast_order = general ? -1 : (fo < 0 ? 0 : fo);
     // one (safe distance, force) for every decay repeller of the batch?  Then the pair goes into the device constants and the lean
     // launches read the uniform image.
@@ -840,8 +870,9 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     a.clamp = clamp ? 1 : 0;
     if (n_cycles > 0 && (io->track_error || io->obj_dist))
         return fail(VFIK_E_ARG, "io->track_error / io->obj_dist are per control cycle: vfik_step only, not a rollout");
-    if (n_cycles > 0 && h->n > VFIK_ROLL_MAX_NJ) {
-        // Long chains: the rollout is n_cycles single-cycle launches, each integrating q on its way out
+    if (n_cycles > 0 && (h->n > VFIK_ROLL_MAX_NJ || !a.plain)) {
+        // Long chains, and (round 4) chains with a tool, IK weights or prismatic joints, whose in-kernel loop spilled 12-268 B per
+        // lane: the rollout is n_cycles single-cycle launches, each integrating q on its way out
         // (q ping-pongs between two device buffers; the caller's io->q is never written).  The kernel has
         // no registers left for loop-carried state at these sizes -- the in-kernel loop spills and is
         // slower than this (C5: 22 us per cycle against 17.4 us).  Outputs are those of the last cycle,
@@ -1313,6 +1344,11 @@ int vfik_field_path(vfik_handle* h) {
     if (!h) return VFIK_E_ARG;
     if (h->fast_order < 0) return 0;
     return h->any_funnel ? 2 : 1;
+}
+
+int vfik_mixed_orders(vfik_handle* h) {
+    if (!h) return VFIK_E_ARG;
+    return (h->fast_order >= 0 && h->mixed) ? 1 : 0;
 }
 
 int vfik_uniform_repellers(vfik_handle* h) {

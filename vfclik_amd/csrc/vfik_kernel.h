@@ -26,6 +26,8 @@ namespace vfik {
 //   hemisphere            3 planes    likewise the arm's ONE hemisphere repeller (object_feeder:344-353): (x y z nx | ny nz safeDist order | force present - -)
 //   slots_fast            3 ceil(S/2) planes  decay repellers only, two slots in three quads: (x0 y0 z0 r0 | s0 f0 x1 y1 | z1 r1 s1 f1);
 //                                     what the straight-line field path reads (24 instead of 32 bytes a slot at float I/O)
+//   orders                ceil(S/16) planes of 16 BYTES per arm (whatever T): byte m % 16 of plane m / 16 = integer decay order of compact-image
+//                                     slot m (< 128; unused slots carry 5): read by the MIXO kernel variants when the batch's orders differ
 //   slots                 2S planes   slot m = planes 2m, 2m+1 = (p0 p1 p2 p3 | p4 p5 force type);
 //                                     type -1 = continuation of the previous slot (p6..p11 / p12..p16),
 //                                     type 0 = empty
@@ -144,6 +146,9 @@ struct KArgs {
     int uni_planes;              // quad planes of the compact image = offset of the uniform image behind slots_fast
     int waves2;                  // 1: lean straight-line float launches of more than n_simd waves take the two-waves-per-SIMD build (VFIK_TWO_WAVES=0: never)
     int pers;                    // 1: lean straight-line launches of more than n_simd waves take the persistent kernel (VFIK_PERSISTENT=0: never)
+    // round 4: decay repellers whose INTEGER orders differ (README.old:75 documents order 20 beside the feeder's 5, object_feeder:302)
+    const void* orders;          // order planes: 16 bytes per arm and plane = the decay orders of 16 slots of the compact image, one byte each
+    int mixed;                   // 1: the batch's repellers do not share one order -- the straight-line path reads `orders` (MIXO kernel variants)
 };
 
 // The per-handle device state a LEAN launch reads lives in ONE allocation with offsets that follow from (io type, joints, Bpad):

@@ -481,8 +481,11 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
     if (nullity == 1) {
         double u[NJ];
         // u <- (I - Q^T Q) u: all six coefficients first (independent dot products), then the update (classical
-        // Gram-Schmidt against an orthonormal Q); returns the largest |coefficient| = how much of u was row space
-        auto project = [&](double* x) {
+        // Gram-Schmidt against an orthonormal Q); returns the largest |coefficient| = how much of u was row space.
+        // `on` (per lane): lanes with on = false keep their x -- their coefficients are zeroed, so one vector serves the arms that
+        // take a path and the arms that do not, IN PLACE (round 4: the copies u2 / uc of the vector and the selects that merged
+        // them cost 28 registers where the kernel has none to spare; same operations for the lanes that take the path, same bits).
+        auto project = [&](double* x, bool on) {
             double c[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) c[r] = 0.0;
@@ -490,6 +493,8 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
             for (int i = 0; i < NJ; ++i)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * x[i];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) c[r] = on ? c[r] : 0.0;
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -512,46 +517,39 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
         // ~ eps cond(J) times what was removed).  An arm without a usable previous vector (first cycle, a
         // jump that leaves less than half of it) takes the cold path below.
         bool warm = false;
-        if (__any(has_vec)) {  // (a stored vector is a unit vector)
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) u[i] = lv_r[i];
-            const double cm = project(u);
+        for (int i = 0; i < NJ; ++i) u[i] = lv_r[i];
+        if (__any(has_vec)) {  // (a stored vector is a unit vector)
+            const double cm = project(u, true);
             nn = norm2(u);
             warm = has_vec && nn > 0.25;
             const bool again = warm && cm > 1e-2;  // a real move: project once more, as the cold path does
             if (__any(again)) {
-                double u2[NJ];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) u2[i] = u[i];
-                project(u2);
-                const double nn2 = norm2(u2);
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) u[i] = again ? u2[i] : u[i];
-                nn = again ? nn2 : nn;
+                project(u, again);
+                nn = norm2(u);      // (unchanged bits for the lanes that did not project again)
             }
         }
         if (__any(!warm)) {
             // cold: the normalised column of the projector with the largest diagonal, projected twice
-            double dg[NJ], uc[NJ];
             double best = -1.0;
             int ib = 0;
+            {
+                double dg[NJ];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) dg[i] = 1.0;
+                for (int i = 0; i < NJ; ++i) dg[i] = 1.0;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) dg[i] -= Jm[i][r] * Jm[i][r];
+                    for (int i = 0; i < NJ; ++i) dg[i] -= Jm[i][r] * Jm[i][r];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i)
-                if (dg[i] > best) { best = dg[i]; ib = i; }
+                for (int i = 0; i < NJ; ++i)
+                    if (dg[i] > best) { best = dg[i]; ib = i; }
+            }
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) uc[i] = (i == ib) ? 1.0 : 0.0;
-            project(uc);  // twice: the second pass squares the residual
-            project(uc);
-            const double nnc = norm2(uc);
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) u[i] = warm ? u[i] : uc[i];
-            nn = warm ? nn : nnc;
+            for (int i = 0; i < NJ; ++i) u[i] = warm ? u[i] : ((i == ib) ? 1.0 : 0.0);
+            project(u, !warm);  // twice: the second pass squares the residual
+            project(u, !warm);
+            nn = norm2(u);
         }
         double nrm, ninv;
         sqrt_rsqrt(nn, nrm, ninv);
@@ -784,9 +782,10 @@ template <typename T> struct SlotLds {
 #define VFIK_SCALAR_KERNARG 1     // 0: every kernel takes its argument block by value, as until round 3 (A/B builds)
 #endif
 #ifdef VFIK_STAMPS
-template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = false; };
+template <int LEAN, bool ROLL, bool FASTF, bool MIXO = false> struct SmallArgs { static constexpr bool value = false; };
 #else
-template <int LEAN, bool ROLL, bool FASTF> struct SmallArgs { static constexpr bool value = LEAN == 1 && !ROLL && FASTF; };
+// (MIXO variants keep the argument block: the order planes' address is one more pointer than KLean's fourteen dwords hold)
+template <int LEAN, bool ROLL, bool FASTF, bool MIXO = false> struct SmallArgs { static constexpr bool value = LEAN == 1 && !ROLL && FASTF && !MIXO; };
 #endif
 template <typename T, int NJ> struct ArenaLayout {
     __host__ __device__ static long funnel_off(long Bpad) { return 4 * Bpad * 4 * (long)sizeof(T); }
@@ -807,15 +806,22 @@ template <typename T, int NJ> struct ArenaLayout {
 // UNI = the straight-line path reading the UNIFORM repeller image: every decay repeller of the batch has the same safe distance and
 // force (object_feeder sends 0.001 and -10 for every point obstacle and for the near-goal repeller: object_feeder:301-302,323,331), so a
 // slot is ONE quad (x y z radius) and the pair travels in the constants -- 16 instead of 24 bytes and two thirds of the requests.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES, bool UNI>
+// MIXO = the straight-line path for decay repellers whose INTEGER orders differ, between slots or between arms (old/README.old:75
+// documents `ObstacleP ... 0.05 20` while the feeder's near-goal repeller has order 5, object_feeder:302).  Every arm carries one byte
+// per compact-image slot in the order planes (vfik_kernel.h), requested behind the goal block; a wave whose 64 arms agree slot by
+// slot -- every scene in which the orders differ by obstacle, not by arm -- raises each slot to ITS power under scalar control
+// flow, the slots in lock step; a wave with an odd arm falls back to per-lane selects over the bits of its largest order.  Until
+// round 4 two different orders anywhere in the batch sent the whole batch to the general path (C3-sized: 7.1 instead of 5.3 us).
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES, bool UNI, bool MIXO>
 __device__ __forceinline__ void
-cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type& a_in) {
+cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, KLean, KArgs>::type& a_in) {
+    static_assert(!MIXO || (FASTF && PLAIN && !ROLL && !PERS && !UNI && WAVES == 1 && (LEAN == 1 || LEAN == 3)), "MIXO: the lean single-cycle straight-line variants");
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
     static_assert(WAVES == 1 || (WAVES == 2 && LEAN == 1 && FASTF && PLAIN && !ROLL && !PERS && !FUN && sizeof(T) == 4 && NJ <= 7), "WAVES 2: lean straight-line float launches only");
     static_assert(!UNI || (FASTF && PLAIN && !ROLL && !PERS && !FUN && (LEAN == 1 || LEAN == 3)), "UNI: the lean single-cycle straight-line variants");
     KArgs a;
-    if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
+    if constexpr (SmallArgs<LEAN, ROLL, FASTF, MIXO>::value) {
         a = KArgs{};
         a.B = a_in.B; a.Bpad = a_in.Bpad; a.slots_used = a_in.slots_used; a.fast_order = a_in.fast_order; a.flags = a_in.flags; a.block = a_in.block;
         a.q = a_in.q; a.qdot_out = a_in.qdot_out; a.status = a_in.status;
@@ -878,7 +884,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     // (LEAN launches run the straight-line path and touch only the head of the region: their waves are packed closer)
     constexpr int FUN_OFF = Stage<T>::lean_bytes(NJ);       // FUN: the aux block's rows sit behind the lean region
     constexpr int NFUN = FUN ? 6 : 0;                       // (funnel 3 + hemisphere 3)
-    constexpr int REGION_BYTES = ((LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ)) + NFUN * Stage<T>::QSTEP;
+    constexpr int NORD = MIXO ? 1 : 0;                      // MIXO: one 1-KiB row for the chunk's 16 order bytes per arm, behind the aux rows
+    constexpr int ORD_OFF = FUN_OFF + NFUN * Stage<T>::QSTEP;
+    constexpr int REGION_BYTES = ((LEAN != 0 && FASTF) ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ)) + NFUN * Stage<T>::QSTEP + NORD * 1024;
     char* const region = lds_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * REGION_BYTES;
     // per-arm inputs (goal block, first-chunk slot quads, q) of the chunk being computed: the head of the region, or
     // (PERS, odd chunks of the wave) the second per-arm area behind the constants and the table
@@ -995,12 +1003,18 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 #pragma unroll
         for (int k = 0; k < NFUN; ++k) stage_quad<T, NTL>(fg + k * planeB, (unsigned)arm * (unsigned)QB, region, FUN_OFF + k * Stage<T>::QSTEP);
     }
+    // MIXO: the 16 order bytes that cover slots [c0 & ~15, +16) of this arm -> the order row (one request whatever T)
+    auto issue_orders = [&](int c0) {
+        const char* og = static_cast<const char*>(a.orders) + (long)(c0 >> 4) * Bp * 16 + (long)arm * 16;
+        __builtin_amdgcn_global_load_lds((GPtr)og, (LPtr)(region + ORD_OFF), 16, 0, NTL ? 2 : 0);
+    };
+    if constexpr (MIXO) issue_orders(0);  // (behind the goal / aux blocks: the goal's wait covers it)
 #pragma unroll
     for (int idx = 0; idx < EARLY_Q; ++idx) issue_slot_quad(idx);
 
     // The members of the argument block the rest of the cycle needs, in one batch of scalar loads behind the requests (cycle_kernel_x:
     // left alone, the compiler fetches each where it is first used -- a round trip to the kernarg segment every time)
-    if constexpr (VFIK_SCALAR_KERNARG && !SmallArgs<LEAN, ROLL, FASTF>::value)
+    if constexpr (VFIK_SCALAR_KERNARG && !SmallArgs<LEAN, ROLL, FASTF, MIXO>::value)
         asm volatile("" ::"s"(a.null_control), "s"(a.qdot_vf), "s"(a.qdot_null), "s"(a.pose), "s"(a.pose_nt), "s"(a.v6), "s"(a.qdist), "s"(a.goal_dist),
                      "s"(a.status), "s"(a.q_out), "s"(a.ext), "s"(a.q_ref), "s"(a.q_cmded), "s"(a.q_lo), "s"(a.q_hi), "s"(a.q_ref_out), "s"(a.wts));
     STAMP(1);
@@ -1024,7 +1038,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
         }
     };
     if constexpr (!PERS) {
-        VFIK_WAIT_VM((4 + NFUN + EARLY_Q) * Q16);  // constants, table, tool and q have landed (the goal, funnel and early slot requests may still be out)
+        VFIK_WAIT_VM((4 + NFUN + EARLY_Q) * Q16 + NORD);  // constants, table, tool and q have landed (the goal, funnel, order and early slot requests may still be out)
         STAMP(2);
         read_q();
     }
@@ -1214,9 +1228,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     constexpr bool FUSEP = NULLSP && NJ >= 8;
     // ... except with IK weights or a tool (general variant), or on the general field path: the undamped Gram matrix G = J J^T and J z are then accumulated in a
     // pass of their own AFTER the IK's solve, when the weighted normal matrix is dead -- both matrices live at once spill
-    constexpr bool GLATE = FUSEP && (!PLAIN || (!FASTF && sizeof(T) == 4));  // (float64 I/O on the general path: 88 B of scratch without it, 176 with)
+    constexpr bool GLATE = FUSEP && (!PLAIN || (!FASTF && sizeof(T) == 4));  // (float64 I/O, PLAIN, general path: 120 B of scratch without it, 108 with -- and slower)
     double zp[FUSEP ? NJ : 1];
-    if constexpr (FUSEP) {
+    // ZLATE (float64 I/O, GLATE): the task's direction is formed where it is used, behind the IK's solve -- 2 n registers less through
+    // field and IK (152 -> 56, 128 -> 32 B of scratch; the float variants got WORSE with it, 76 -> 128, and keep the early form)
+    constexpr bool ZLATE = GLATE && sizeof(T) == 8;
+    if constexpr (FUSEP && !ZLATE) {
         const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) zp[i] = 0.0;
@@ -1480,6 +1497,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
             auto chunk = [&](int c0) {
                 const int ncur = a.slots_used - c0;  // slots of this chunk that are in use (may exceed PRE)
                 double dx[PRE], dy[PRE], dz[PRE], rs[PRE], fk[PRE];
+                unsigned ow[MIXO ? PRE / 4 : 1];     // MIXO: this chunk's decay orders, one byte a slot
+                if constexpr (MIXO) {
+                    const char* orow = region + ORD_OFF + lanec * 16 + (c0 & 15);
+#pragma unroll
+                    for (int u = 0; u < PRE / 4; ++u) ow[u] = *reinterpret_cast<const unsigned*>(orow + 4 * u);
+                }
                 if constexpr (UNI) {  // a slot = one quad (x y z radius | radius = -inf: unused); safe distance and force are the batch's (KConst)
                     const double usafe = kl->rep_safe, uforce = kl->dh[0].pad;
 #pragma unroll
@@ -1517,6 +1540,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
                         const char* sm = slots0 + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
                         stage_quad<T, NTL>(sm, (unsigned)arm * (unsigned)QB, dreg, Stage<T>::slot_off(idx, NJ));
                     }
+                    if constexpr (MIXO) issue_orders(c0 + PRE);   // (the row's bytes of this chunk are in registers)
                 }
                 double di[PRE], rb[PRE], rp[PRE];
 #pragma unroll
@@ -1525,6 +1549,104 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
                     rb[m] = rs[m] * di[m];
                     rp[m] = 1.0;
                 }
+                if constexpr (MIXO) {
+                    // do the wave's 64 arms agree on every order of the chunk?  (the words compared whole: two or one)
+                    unsigned su[PRE / 4];
+                    bool agree = true;
+#pragma unroll
+                    for (int u = 0; u < PRE / 4; ++u) {
+                        su[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)ow[MIXO ? u : 0]);
+                        agree = agree && __all(ow[MIXO ? u : 0] == su[u]);
+                    }
+                    // Wave-uniform orders, at most TWO distinct ones in the chunk (the README's scene: order-20 obstacles beside the feeder's
+                    // order-5 near-goal repeller): one pass per distinct order under scalar control flow -- rb^o for all slots in lock step,
+                    // then the slots with that order take their value by a select on a scalar condition.  Three or more distinct orders,
+                    // or an arm with an order of its own: per-lane selects over the bits of the largest order (a pass costs ~0.3 us of a
+                    // 5.3-us launch, the bit-serial form ~0.9 us whatever the number of orders: profiles/r04_ab_experiments.md; a first
+                    // version that tested every (slot, bit) pair with a scalar branch cost 1.0 us for two orders).
+                    bool lanes = !agree;
+                    if (agree) {
+                        bool all5 = true;
+#pragma unroll
+                        for (int u = 0; u < PRE / 4; ++u) all5 = all5 && su[u] == 0x05050505u;
+                        auto order_of = [&](int m) { return ((m < 4 ? su[0] : su[PRE / 4 - 1]) >> (8 * (m & 3))) & 127u; };
+                        auto fifth = [&](double* dst) {
+#pragma unroll
+                            for (int m = 0; m < PRE; ++m) { const double b2 = rb[m] * rb[m]; dst[m] = b2 * b2 * rb[m]; }
+                        };
+                        const unsigned o1 = order_of(0);
+                        unsigned todo = 0, rest = 0, o2 = o1;
+                        if (!all5) {
+#pragma unroll
+                            for (int m = 1; m < PRE; ++m) todo |= (order_of(m) != o1 ? 1u : 0u) << m;
+                            if (todo) {
+                                o2 = order_of(__builtin_ctz(todo));
+#pragma unroll
+                                for (int m = 1; m < PRE; ++m) rest |= ((todo >> m) & 1u && order_of(m) != o2 ? 1u : 0u) << m;
+                            }
+                        }
+                        lanes = rest != 0;
+                        if (all5) {
+                            fifth(rp);
+                        } else if (!lanes) {
+                            auto raise_all = [&](unsigned o, double* dst) {   // left-to-right binary: the control flow depends on o alone
+                                if (o <= 1) {
+#pragma unroll
+                                    for (int m = 0; m < PRE; ++m) dst[m] = o ? rb[m] : 1.0;
+                                    return;
+                                }
+                                int k = 30 - __builtin_clz(o);        // the bit below the leading one (o >= 2: k >= 0)
+#pragma unroll
+                                for (int m = 0; m < PRE; ++m) dst[m] = rb[m] * rb[m];
+                                for (;;) {
+                                    if ((o >> k) & 1u) {
+#pragma unroll
+                                        for (int m = 0; m < PRE; ++m) dst[m] *= rb[m];
+                                    }
+                                    if (--k < 0) break;
+#pragma unroll
+                                    for (int m = 0; m < PRE; ++m) dst[m] *= dst[m];
+                                }
+                            };
+                            if (o1 == 5) fifth(rp);
+                            else raise_all(o1, rp);          // the first order: every slot takes it, no select
+                            if (todo) {
+                                double pw[PRE];
+                                // an order that is 2^j times the first (20 after 5): j squarings of the first pass's powers
+                                const unsigned ratio = o1 ? o2 / o1 : 0u;
+                                if (ratio > 1 && ratio * o1 == o2 && (ratio & (ratio - 1)) == 0) {
+#pragma unroll
+                                    for (int m = 0; m < PRE; ++m) pw[m] = rp[m] * rp[m];
+                                    for (unsigned r = ratio >> 1; r > 1; r >>= 1) {
+#pragma unroll
+                                        for (int m = 0; m < PRE; ++m) pw[m] *= pw[m];
+                                    }
+                                } else {
+                                    raise_all(o2, pw);
+                                }
+#pragma unroll
+                                for (int m = 1; m < PRE; ++m) rp[m] = (todo >> m) & 1u ? pw[m] : rp[m];
+                            }
+                        }
+                    }
+                    if (lanes) {
+                        int nn[PRE], nmax = 0;
+#pragma unroll
+                        for (int m = 0; m < PRE; ++m) { nn[m] = (int)((ow[MIXO ? (m >> 2) : 0] >> (8 * (m & 3))) & 127u); nmax |= nn[m]; }
+                        int top = 0;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                            if (__any((nmax >> k) != 0)) top = k + 1;
+                        for (int k = 0; k < top; ++k) {
+#pragma unroll
+                            for (int m = 0; m < PRE; ++m) rp[m] = (nn[m] >> k) & 1 ? rp[m] * rb[m] : rp[m];
+                            if (k + 1 < top) {
+#pragma unroll
+                                for (int m = 0; m < PRE; ++m) rb[m] *= rb[m];
+                            }
+                        }
+                    }
+                } else
                 if (n0 == 5) {  // what object_feeder sends (object_feeder:302,333): no loop, no branches
 #pragma unroll
                     for (int m = 0; m < PRE; ++m) { const double b2 = rb[m] * rb[m]; rp[m] = b2 * b2 * rb[m]; }
@@ -1643,7 +1765,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
     // The nullspace state is requested HERE, a phase ahead of the module that uses it (the IK's solve covers the round trip;
     // requested in front of the Gram-Schmidt block, as in round 2, the launch is 2.0 % slower with the inputs in HBM, 0.3 %
     // with them in the Infinity Cache: profiles/r03_ab_experiments.md).  A rollout loads it once, before its cycles.
-    if constexpr (NULLSP && NJ <= 7 && !ROLL) load_null_state();
+    // (the two-waves-per-SIMD build has 256 registers a lane: it requests the state where the module starts -- its co-resident wave
+    // covers the round trip -- instead of holding 8 more registers through the solve: 28 B of scratch per lane otherwise)
+    if constexpr (NULLSP && NJ <= 7 && !ROLL && WAVES == 1) load_null_state();
     // normCart + speedScale * scalars (vf:292,346-347)
     double v[3], w[3];
     {
@@ -1686,6 +1810,15 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
         }
         if constexpr (GLATE) {
             asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]));  // (behind the solve)
+            if constexpr (ZLATE) {   // the joint-limit task's direction, from the joint angles in the wave's LDS rows
+                const bool jlt = a.flags & VFIK_F_JOINT_LIMIT_TASK;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) zp[FUSEP ? i : 0] = 0.0;
+                if (jlt) {
+                    if constexpr (NJ >= 10 && !ROLL) read_q();
+                    jl_descent(zp);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 wn[r] = 0.0;
@@ -1787,6 +1920,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
             for (int i = 0; i < NJ; ++i)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(Jm[i][r]) : "v"(qv[0]));
+            if constexpr (!ROLL && WAVES == 2) load_null_state();
             double c0 = 0.0;
             if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
             const bool advanced = nullspace_core<NJ>(Jm, lv_r, sig_r, has_vec, c0, (a.flags & VFIK_F_JOINT_LIMIT_TASK) != 0, jl_descent, qn, status);
@@ -2032,10 +2166,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, 
 }
 
 // The kernel proper: the body above behind an argument block (KArgs, or KLean for the lean single-cycle straight-line variants) ...
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false, bool MIXO = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::type a_in) {
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(a_in);
+cycle_kernel(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, KLean, KArgs>::type a_in) {
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI, MIXO>(a_in);
 }
 // ... or, for the KLean variants, behind KLean's ten members as SCALAR kernel arguments: those the command processor can preload into
 // the wave's SGPRs at dispatch (-amdgpu-kernarg-preload-count, Makefile; an argument block passed by value is never preloaded), which
@@ -2047,7 +2181,7 @@ cycle_kernel_s(const void* base, const void* q, void* qdot_out, int* status, int
     KLean k;
     k.base = base; k.q = q; k.qdot_out = qdot_out; k.status = status;
     k.B = B; k.Bpad = Bpad; k.slots_used = slots_used; k.fast_order = fast_order; k.flags = flags; k.block = block;
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(k);
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI, false>(k);
 }
 // The members of the handle's state arena and the launch's first arguments, from scalars (the arena's layout: vfik_kernel.h)
 template <typename T, int NJ>
@@ -2064,18 +2198,32 @@ __device__ __forceinline__ void args_from_scalars(KArgs& a, const void* base, co
 }
 // Every other variant: the same ten scalars IN FRONT of the argument block -- what the prologue needs to issue its first requests (the
 // arena's members, q, the sizes) arrives preloaded; the rest of the block is read by scalar loads that run under those requests.
-template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false>
+template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false, bool MIXO = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 cycle_kernel_x(const void* base, const void* q, void* qdot_out, const int* active, int B, int Bpad, int slots_used, int fast_order, unsigned flags, int block,
                const KArgs a_in) {
-    static_assert(!SmallArgs<LEAN, ROLL, FASTF>::value, "the KLean variants take cycle_kernel_s");
+    static_assert(!SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, "the KLean variants take cycle_kernel_s");
     KArgs a = a_in;
     args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
     a.active = active;   // (the fresh-q gate is the first request of the prologue; status is stored last and stays in the block)
     a.fast_order = fast_order; a.block = block;
-    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI>(a);
+    cycle_body<T, NJ, NULLSP, PLAIN, ROLL, FASTF, LEAN, CF, PERS, FUN, WAVES, UNI, MIXO>(a);
 }
 
+// The MIXO variants: the order planes' address is needed in the REQUEST phase, so it travels among the preloaded scalars too (read from
+// the argument block it cost the prologue the scalar-load round trip that the preload exists to avoid); the launch is made with
+// 64-thread blocks, which frees the two dwords of `fast_order` (unused: the orders are per slot) and `block`.
+template <typename T, int NJ, bool NULLSP, int LEAN, bool FUN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+cycle_kernel_m(const void* base, const void* q, void* qdot_out, const int* active, const void* orders, int B, int Bpad, int slots_used, unsigned flags,
+               const KArgs a_in) {
+    KArgs a = a_in;
+    args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
+    a.active = active;
+    a.orders = orders;
+    a.fast_order = 0; a.block = 64;
+    cycle_body<T, NJ, NULLSP, true, false, true, LEAN, -1, false, FUN, 1, false, true>(a);
+}
 
 // CommandMixer.read's weighted sum alone (command_mixer.py:78-82): out = sum_k cmd[k] * w[k], left to
 // right from 0.0, multiply and add rounded separately (what CPython does).
@@ -2629,18 +2777,18 @@ void launch_lean(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t
 }
 
 // Launch of any other variant: the prologue's arguments as scalars in front of the argument block, or the block alone
-template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, bool UNI = false>
+template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, bool UNI = false, bool MIXO = false>
 void launch_full(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
-    if constexpr (SmallArgs<LEAN, ROLL, FASTF>::value) {
+    if constexpr (SmallArgs<LEAN, ROLL, FASTF, MIXO>::value) {
         launch_lean<T, NJ, NS, PL, CF, PERS, FUN, 1, UNI>(a_in, grid, blk, lds, stream);
     } else {
         KArgs a = a_in;
         if constexpr (UNI) a.fast_order = (a.fast_order & 255) | (a.uni_planes << 8);
         if constexpr (VFIK_SCALAR_KERNARG) {
-            hipLaunchKernelGGL((cycle_kernel_x<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out,
+            hipLaunchKernelGGL((cycle_kernel_x<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI, MIXO>), grid, blk, lds, stream, (const void*)a.arena, a.q, a.qdot_out,
                                a.active, a.B, a.Bpad, a.slots_used, a.fast_order, a.flags, a.block, a);
         } else {
-            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI>), grid, blk, lds, stream, a);
+            hipLaunchKernelGGL((cycle_kernel<T, NJ, NS, PL, ROLL, FASTF, LEAN, CF, PERS, FUN, 1, UNI, MIXO>), grid, blk, lds, stream, a);
         }
     }
 }
@@ -2662,10 +2810,21 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         if (lean13) fun = true;
         else { fastf = false; a.fast_order = -1; }
     }
+    // decay orders that differ (between slots or arms): the MIXO variants serve the lean and the publishing-lean single-cycle launches
+    // of PLAIN chains, with or without the aux block; every other launch of such a batch takes the general path
+    bool mixo = false;
+    if (fastf && a.mixed) {
+        bool lean13 = false;
+        if constexpr (PL)
+            lean13 = (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.q_lo && !a.q_ref_out &&
+                     !a.q_out && a.n_cycles == 0;
+        if (lean13) mixo = true;
+        else { fastf = false; fun = false; a.fast_order = -1; }
+    }
     if (fastf) a.slots_used = a.slots_used_fast;  // (the straight-line path counts the slots of the compact image)
     // every decay repeller of the batch with one safe distance and one force (what the object feeder sends): the lean single-cycle
     // variants read the uniform image -- one quad per slot, the pair in the constants (cycle_body, UNI)
-    const bool uni = fastf && !fun && a.uni;
+    const bool uni = fastf && !fun && !mixo && a.uni;
     // LEAN launches touch only the head of the region.  They ask for no more than that while the launch is at most one
     // wave per SIMD (C5 -2 %, C3N -0.6 %, C3 +-0 at 65 536 arms); beyond, the full size keeps the launch in rounds of one
     // wave per SIMD -- with eight waves resident per CU a 131 072-arm launch took 12.5 instead of 11.0 us (two waves
@@ -2677,13 +2836,14 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.active && !a.q_lo &&
                !a.q_ref_out;
     lean = lean_any && fastf;
-    if constexpr (NJ <= VFIK_ROLL_MAX_NJ) {
+    // In-kernel rollouts (ROLL) exist for PLAIN chains of up to 7 joints; with a tool, IK weights or prismatic joints the loop-carried
+    // state no longer fits the registers (12-268 B of scratch per lane until round 3) and the rollout is stepped by the host side
+    // (vfik_abi.cpp, launch_cycles), as for the long chains.
+    if constexpr (NJ <= VFIK_ROLL_MAX_NJ && PL) {
         if (a.n_cycles > 0) {
-            if constexpr (PL) {
-                if (lean) {
-                    launch_full<T, NJ, NS, PL, true, true, 1>(a, grid, blk, lds_lean, stream);
-                    return;
-                }
+            if (lean) {
+                launch_full<T, NJ, NS, PL, true, true, 1>(a, grid, blk, lds_lean, stream);
+                return;
             }
             if (fastf) launch_full<T, NJ, NS, PL, true, true, 0>(a, grid, blk, lds, stream);
             else launch_full<T, NJ, NS, PL, true, false, 0>(a, grid, blk, lds, stream);
@@ -2693,7 +2853,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
     if constexpr (PL && NJ <= (NS ? 7 : 8)) {
         // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
         // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
-        const bool served = fastf && !fun && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
+        const bool served = fastf && !fun && !mixo && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
                             !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
                             (NS || (a.flags == 0 && !a.null_control));
         // Adopted where the same-box A/B wins (profiles/r03_latency_small_*.txt, 1 ... 4 096 arms): launches that publish the
@@ -2711,6 +2871,25 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             else
                 hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
             if (sub8) *sub8 = 1;
+            return;
+        }
+    }
+    if constexpr (PL) {
+        if (mixo) {   // (run-time flags: the compile-time flag sets of the default process set are worth ~1 % and a dozen more kernels)
+            const bool lean1 = lean_any && !a.q_out;
+            const dim3 g64((unsigned)((a.B + 63) / 64)), b64(64);    // one wave per block (cycle_kernel_m)
+            size_t lds_m = (long)g64.x <= (long)a.n_simd ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);   // (beyond one wave per SIMD: rounds, as above)
+            if (fun) lds_m = std::max(lds_m, (size_t)(Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
+            lds_m += 1024;
+            a.block = 64;
+#define VFIK_LAUNCH_M(LEANV, FUNV)                                                                                                              \
+    hipLaunchKernelGGL((cycle_kernel_m<T, NJ, NS, LEANV, FUNV>), g64, b64, lds_m, stream, (const void*)a.arena, a.q, a.qdot_out, a.active, a.orders, a.B, \
+                       a.Bpad, a.slots_used, a.flags, a)
+            if (lean1 && fun) VFIK_LAUNCH_M(1, true);
+            else if (lean1) VFIK_LAUNCH_M(1, false);
+            else if (fun) VFIK_LAUNCH_M(3, true);
+            else VFIK_LAUNCH_M(3, false);
+#undef VFIK_LAUNCH_M
             return;
         }
     }
@@ -2738,15 +2917,19 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             // compiler then hoists the joint-limit task's constants over the whole kernel -- and keeps them run-time)
             if constexpr (sizeof(T) == 4 && NJ <= 7) {
                 // beyond one wave per SIMD: the two-waves-per-SIMD build, two blocks' lean regions resident per CU
-                if (a.waves2 && (long)grid.x * (blk.x / 64) > (long)a.n_simd) {
+                // (with the nullspace module only on the uniform repeller image: the compact-image variants of that build spilled 6 registers
+                // per lane for 2-6 % -- they stay in rounds of one wave per SIMD)
+                if (a.waves2 && (long)grid.x * (blk.x / 64) > (long)a.n_simd && (!NS || uni)) {
                     const size_t lds2 = (size_t)(blk.x / 64) * Stage<T>::lean_bytes(NJ);
                     constexpr int NSMIX = VFIK_F_NULLSPACE | VFIK_F_MIXER, NSJLMIX = NSMIX | VFIK_F_JOINT_LIMIT_TASK;
-                    if (NS && a.flags == (unsigned)NSMIX)
-                        { if (uni) launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, NS ? NSMIX : -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
-                    else if (NS && a.flags == (unsigned)NSJLMIX)
-                        { if (uni) launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, NS ? NSJLMIX : -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
-                    else
-                        { if (uni) launch_lean<T, NJ, NS, PL, -1, false, false, 2, true>(a, grid, blk, lds2, stream); else launch_lean<T, NJ, NS, PL, -1, false, false, 2, false>(a, grid, blk, lds2, stream); }
+                    if constexpr (NS) {
+                        if (a.flags == (unsigned)NSMIX) launch_lean<T, NJ, NS, PL, NSMIX, false, false, 2, true>(a, grid, blk, lds2, stream);
+                        else if (a.flags == (unsigned)NSJLMIX) launch_lean<T, NJ, NS, PL, NSJLMIX, false, false, 2, true>(a, grid, blk, lds2, stream);
+                        else launch_lean<T, NJ, NS, PL, -1, false, false, 2, true>(a, grid, blk, lds2, stream);
+                    } else {
+                        if (uni) launch_lean<T, NJ, NS, PL, -1, false, false, 2, true>(a, grid, blk, lds2, stream);
+                        else launch_lean<T, NJ, NS, PL, -1, false, false, 2, false>(a, grid, blk, lds2, stream);
+                    }
                     return;
                 }
             }
@@ -2817,6 +3000,7 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     const dim3 grid((a.B + block - 1) / block), blk(block);
     const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     const bool ns = a.flags & VFIK_F_NULLSPACE;
+    if (a.n_cycles > 0 && (!a.plain || NJ > VFIK_ROLL_MAX_NJ)) return hipErrorInvalidValue;   // (stepped by the caller: launch_cycles)
     if (a.plain) {
         if (ns) launch_v<T, NJ, true, true>(a, grid, blk, lds, stream, sub8);
         else launch_v<T, NJ, false, true>(a, grid, blk, lds, stream, sub8);

@@ -81,6 +81,7 @@ def load_library(path=None):
         "vfik_slots_in_use": (C.c_int, [H]),
         "vfik_field_path": (C.c_int, [H]),
         "vfik_uniform_repellers": (C.c_int, [H]),
+        "vfik_mixed_orders": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
         "vfik_host_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_host_free": (C.c_int, [H, C.c_void_p]),
@@ -243,6 +244,11 @@ class Engine:
         return bool(self.lib.vfik_uniform_repellers(self.h))
 
     @property
+    def mixed_orders(self):
+        """True when the batch's decay repellers have integer orders that differ (the order planes are read; ABI 5)."""
+        return bool(self.lib.vfik_mixed_orders(self.h))
+
+    @property
     def device_bytes(self):
         return self.lib.vfik_device_bytes(self.h)
 
@@ -326,17 +332,23 @@ class Engine:
         buf = (C.c_char * max(nbytes, 1)).from_address(p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def submit_host(self, q, outs, null_control=None, q_ref=None, q_cmded=None):
+    def submit_host(self, q, outs, null_control=None, q_ref=None, q_cmded=None, active=None, q_lo=None, q_hi=None):
         """Asynchronous vfik_step_host: ``q`` and the arrays of ``outs`` ({"qdot_out": array, ...}) must
-        be C-contiguous arrays of the engine's dtype (``status``: int32) that stay untouched until
-        :meth:`wait` -- use :meth:`host_array` for overlap.  Returns the ticket."""
+        be C-contiguous arrays of the engine's dtype (``status`` and ``active``: int32) that stay untouched until
+        :meth:`wait` -- use :meth:`host_array` (pinned memory) for overlap: copies from / to pageable memory make the
+        call synchronous.  Returns the ticket."""
         io = IO()
         for name, arr, cols in (("q", q, self.n), ("null_control", null_control, _abi.NULL_CONTROLS), ("q_ref", q_ref, self.n),
-                                ("q_cmded", q_cmded, self.n)):
+                                ("q_cmded", q_cmded, self.n), ("q_lo", q_lo, self.n), ("q_hi", q_hi, self.n)):
             if arr is None:
                 continue
             self._check_host(name, arr, (self.batch, cols), self.io_dtype)
             setattr(io, name, arr.ctypes.data)
+        if (q_lo is None) != (q_hi is None):
+            raise ValueError("q_lo and q_hi come together")
+        if active is not None:
+            self._check_host("active", active, (self.batch,), np.int32)
+            io.active = active.ctypes.data
         for k, arr in outs.items():
             if k == "status":
                 self._check_host(k, arr, (self.batch,), np.int32)

@@ -226,3 +226,68 @@ def main_spawn(script, args, world, timeout=None):
     if rc == 124:
         print("%s: the %d ranks did not finish within %.0f s; terminated" % (os.path.basename(script), world, timeout), file=sys.stderr)
     return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Which backend carries the barrier and the timing reductions of a multi-rank job (bench.py; the control path has no
+# collective).  RCCL's communicator is brought up by a COLLECTIVE call (ncclCommInitRank) that has no timeout of its
+# own: a rank that fails before it leaves its peers inside it for good.  So the ranks agree through the rendezvous
+# store -- plain key/value traffic, no collective -- BEFORE anyone enters it: every rank publishes a local pre-check
+# (RCCL importable, its device usable, which physical device it holds), reads everybody's, and all take the same
+# decision from the same data.  Only when every pre-check passed is the communicator tried, under a watchdog that
+# ends the process (non-zero) if the attempt does not finish within a bound, so that a rank whose peer died inside
+# the collective exits instead of waiting.
+# ------------------------------------------------------------------------------------------------------------------
+def decide_backend(prechecks):
+    """prechecks: one (ok, why, device_id) per rank, in rank order -> ("nccl" | "gloo", reason).  RCCL only when every
+    rank's pre-check passed and no two ranks hold the same physical device (RCCL refuses two ranks on one GPU)."""
+    for r, (ok, why, _dev) in enumerate(prechecks):
+        if not ok:
+            return "gloo", "rank %d: %s" % (r, why or "pre-check failed")
+    seen = {}
+    for r, (_ok, _why, dev) in enumerate(prechecks):
+        if dev and dev in seen:
+            return "gloo", "ranks %d and %d share device %s" % (seen[dev], r, dev)
+        seen[dev] = r
+    return "nccl", ""
+
+
+def agree_on_backend(store, rank, world, precheck, timeout_s=120.0, prefix="pg_pre"):
+    """Publish this rank's pre-check, read every rank's, decide.  `store`: a torch.distributed store (set / get; get blocks
+    until the key exists or the store's timeout passes -- set here to `timeout_s`, so a rank that never publishes costs its
+    peers a bounded wait and an exception, not a hang).  Returns (backend, reason, prechecks)."""
+    import datetime
+    ok, why, dev = precheck
+    store.set_timeout(datetime.timedelta(seconds=timeout_s))
+    store.set("%s_%d" % (prefix, rank), "%d|%s|%s" % (1 if ok else 0, (why or "").replace("|", "/")[:160], (dev or "").replace("|", "/")))
+    got = []
+    for r in range(world):
+        o, w, d = store.get("%s_%d" % (prefix, r)).decode().split("|", 2)
+        got.append((o == "1", w, d))
+    backend, reason = decide_backend(got)
+    return backend, reason, got
+
+
+class Watchdog:
+    """Ends the PROCESS (os._exit(code)) if not cancelled within `seconds`: for calls that cannot be interrupted from Python
+    (a collective communicator start whose peer is gone).  A fresh daemon thread; the parent launcher sees the exit code and
+    terminates the other ranks (spawn_ranks)."""
+
+    def __init__(self, seconds, what, code=3, log=None):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self.what, self.code, self.seconds = what, code, seconds
+        self.log = log or (lambda m: print(m, file=sys.stderr, flush=True))
+
+    def _fire(self):
+        self.log("[watchdog] %s did not finish within %.0f s: exiting with code %d" % (self.what, self.seconds, self.code))
+        os._exit(self.code)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+        return False

@@ -132,6 +132,42 @@ class Bottle:
         return len(self._items)
 
 
+class ArrayBottle:
+    """A bottle of doubles (and trailing ints) backed by ONE array row: what a module that publishes thousands of bottles per cycle
+    hands to its ports (vfclik_amd.vf_module).  The Value objects are made when a reader asks for them, not when the bottle is
+    written -- a reader sees exactly what it would see in a Bottle built with addDouble / addInt.  Immutable: delivery shares it."""
+    __slots__ = ("_a", "_ints")
+
+    def __init__(self, row, ints=()):
+        self._a = row
+        self._ints = tuple(ints)
+
+    def size(self):
+        return len(self._a) + len(self._ints)
+
+    __len__ = size
+
+    def get(self, i):
+        n = len(self._a)
+        if 0 <= i < n:
+            return Value(float(self._a[i]))
+        if n <= i < n + len(self._ints):
+            return Value(int(self._ints[i - n]))
+        return Value(None)
+
+    def toString(self):
+        return " ".join(self.get(i).toString() for i in range(self.size()))
+
+    def tolist(self):
+        return [float(v) for v in self._a] + [int(v) for v in self._ints]
+
+    def copy(self):
+        return self
+
+    def __bool__(self):
+        return True
+
+
 class ContactStyle:
     def __init__(self):
         self.persistent = False
@@ -144,11 +180,13 @@ class _Registry:
         self.lock = threading.RLock()
         self.ports = {}
         self.links = collections.defaultdict(set)  # source name -> destination names
+        self.version = 0   # bumped whenever a port opens / closes or a connection changes: "who listens" caches key on it
 
     def reset(self):
         with self.lock:
             self.ports.clear()
             self.links.clear()
+            self.version += 1
 
 
 _REG = _Registry()
@@ -167,12 +205,14 @@ class Network:
     def connect(src, dst, style=None):
         with _REG.lock:
             _REG.links[src].add(dst)
+            _REG.version += 1
         return True
 
     @staticmethod
     def disconnect(src, dst):
         with _REG.lock:
             _REG.links[src].discard(dst)
+            _REG.version += 1
         return True
 
     @staticmethod
@@ -198,18 +238,21 @@ class BufferedPortBottle:
         self._queue = collections.deque()
         self._cond = threading.Condition(_REG.lock)
         self._out = Bottle()
+        self._mail = None   # (list, key): the owner's index of ports with unread mail (set_mailbox)
 
     # -- life cycle --
     def open(self, name):
         with _REG.lock:
             self._name = name
             _REG.ports[name] = self
+            _REG.version += 1
         return True
 
     def close(self):
         with _REG.lock:
             if self._name and _REG.ports.get(self._name) is self:
                 del _REG.ports[self._name]
+                _REG.version += 1
             self._name = None
 
     def getName(self):
@@ -235,11 +278,31 @@ class BufferedPortBottle:
     def writeStrict(self):
         self.write(True)
 
+    def write_bottle(self, bottle, strict=False):
+        """Deliver a ready-made (immutable) bottle -- an ArrayBottle -- to every connected reader."""
+        with _REG.lock:
+            for dst in _REG.links.get(self._name, ()):
+                port = _REG.ports.get(dst)
+                if port is not None:
+                    port._deliver(bottle, strict)
+
+    def has_readers(self):
+        """True when some OPEN port is connected behind this one (a write to a port nobody reads is dropped, as in YARP)."""
+        with _REG.lock:
+            return any(dst in _REG.ports for dst in _REG.links.get(self._name, ()))
+
+    def set_mailbox(self, box, key):
+        """Owner-side index of pending mail: every delivery to this port appends `key` to the list `box`, so that a module with
+        thousands of input ports visits only those that received something (vfclik_amd.vf_module.ControlCycleBatch._poll)."""
+        self._mail = (box, key)
+
     def _deliver(self, bottle, strict):
         with self._cond:
             if not (self._strict or strict):
                 self._queue.clear()  # only the newest message survives on a non-strict reader
             self._queue.append(bottle)
+            if self._mail is not None:
+                self._mail[0].append(self._mail[1])
             self._cond.notify_all()
 
     # -- reading --
@@ -269,3 +332,8 @@ class Time:
 
 def Time_delay(s):  # nullspace:187
     _time.sleep(s)
+
+
+def registry_version():
+    """Changes whenever a port opens / closes or a connection is made / removed (not a YARP call)."""
+    return _REG.version
