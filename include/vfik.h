@@ -233,7 +233,11 @@ int vfik_object_distances(vfik_handle* h, const void* pose, const void* frames, 
  * only when a message changed them: host frames[n_arms][n_objects][16] doubles (row-major 4x4; unused slots: any finite
  * frame, e.g. identity) for the arms [first_arm, first_arm + n_arms).  n_objects (1..4096) is one number for the batch; a
  * call with another n_objects than the handle holds must cover every arm.  io->obj_dist of a cycle call then gets every
- * arm's distances to its objects, computed on the device from the pose of that cycle. */
+ * arm's distances to its objects, computed on the device from the pose of that cycle.  Arms gated off by io->active get no new
+ * pose, hence no new distances either: their rows of obj_dist (like those of track_error) keep the caller's content (ABI 5; until
+ * then they were computed from the arm's previous pose).  The device buffers behind io->track_error / io->obj_dist are allocated
+ * at the first call that asks for them -- a host that CAPTURES vfik_step into a hipGraph makes one such call outside the capture
+ * first (VFIK_E_STATE otherwise). */
 int vfik_set_objects(vfik_handle* h, int first_arm, int n_arms, const double* frames, int n_objects);
 
 /* CommandMixer.read's weighted sum on its own (command_mixer.py:78-82): device cmds[K][B][n],
@@ -283,6 +287,21 @@ int vfik_uniform_repellers(vfik_handle* h);
  * selects); every other launch of such a batch (rollouts, per-arm options) takes the general path.  0 otherwise -- also with the
  * environment variable VFIK_MIXED_ORDERS=0, which restores the behaviour of ABI 4 (differing orders -> field path 0). */
 int vfik_mixed_orders(vfik_handle* h);
+/* ABI 5.  A counter that moves with every call that can change what a cycle launch bakes in at enqueue time -- the kernel variant and
+ * its scalar arguments: field path, uniform / compact / order-plane image, slots in use, flags, PLAIN or not, per-arm option buffers
+ * (tool, weights, mixer state, external commands), the small-batch thresholds -- i.e. every vfik_set_* call, vfik_reset_state and
+ * vfik_set_small_batch_kernel.  A host that CAPTURED vfik_step / vfik_rollout launches into a hipGraph compares the value at capture
+ * with the current one before a replay: a graph captured under another epoch may launch a stale variant (e.g. the uniform-image
+ * kernel after one arm's (safe distance, force) pair changed) and must be re-captured.  Data the launch reads through pointers that
+ * stay (q, the field images' CONTENT, nullspace state, external commands once allocated) needs no re-capture; the epoch moves anyway:
+ * it is conservative. */
+long vfik_launch_epoch(vfik_handle* h);
+/* ABI 5, introspection.  1 when the chain set by vfik_set_chain matches a Denavit-Hartenberg pattern the lean float32-I/O kernels are
+ * built for -- for 7 joints the KUKA LWR 4+ (vfclik's default robot, scripts/vfclik:42): a = 0 on every link, alpha = +-pi/2 on six,
+ * d = 0 on three; for 14 joints two of them in series; for 6 joints the arm of vfclik_amd/robots.py -- and launches may take the
+ * variants in which those links cost no arithmetic (all-revolute chain, identity tool, unit IK weights only); 0 otherwise: every
+ * chain runs, the general DH form is the fallback.  VFIK_DH_PATTERN=0 in the environment switches the specialisation off. */
+int vfik_dh_pattern(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);
 
 #ifdef __cplusplus

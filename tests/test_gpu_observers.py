@@ -156,7 +156,7 @@ def test_observers_fused_into_the_cycle_call(dt, tol):
     eng.set_objects(frames)
     est = [vn.TrackingError() for _ in range(B)]
     q = w["q"].copy()
-    outs = None
+    outs = prev = None
     seen = 0
     for t in range(K):
         active = rng.uniform(size=B) > 0.2 if t % 3 == 1 else None
@@ -166,8 +166,13 @@ def test_observers_fused_into_the_cycle_call(dt, tol):
             outs = {k: v for k, v in outs.items() if k in want}
         out = eng.step_host(q, want=want, active=active, into=outs)
         ref_full = eng.step_host(q, want=("pose", "v6"))  # the same cycle's pose / twist (stateless outputs) for the restatement
-        outs = dict(out)
         act = np.ones(B, dtype=bool) if active is None else active
+        if outs is not None and not act.all():
+            # a gated arm got no new pose: its distances and its tracking error keep what the caller's arrays held (ABI 5; until then
+            # obj_dist was recomputed from the arm's previous pose)
+            assert np.array_equal(out["obj_dist"][~act], prev["obj_dist"][~act]) and np.array_equal(out["track_error"][~act], prev["track_error"][~act])
+        outs = dict(out)
+        prev = {k: v.copy() for k, v in out.items()}
         for b in range(B):
             if not act[b]:
                 continue

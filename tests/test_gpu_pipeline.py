@@ -101,11 +101,16 @@ def test_vfik_step_is_capturable_into_a_hip_graph():
             with torch.cuda.graph(graph, stream=s):
                 for _ in range(5):
                     eng.step(io_g)
+            epoch = eng.launch_epoch
             for _ in range(3):
                 out_g.zero_()
                 graph.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(out_g, out_d)
+            # what the capture baked in is valid for the handle's launch epoch: replays do not move it, a vfik_set_* call does
+            assert eng.launch_epoch == epoch
+            eng.set_fields(w["fields"], w["nfields"])
+            assert eng.launch_epoch > epoch
         eng.close()
 
 

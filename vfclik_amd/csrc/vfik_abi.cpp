@@ -59,6 +59,7 @@ struct vfik_handle {
     int sub8_max_batch_ns = 32;      // with the nullspace module and qdot_out only: a handful of arms (-7 ... -11 %), even from 64 on
     int sub8_max_batch_full = 4096;  // launches that publish the per-cycle rows: -18 ... -22 % at every size (vfik_set_small_batch_kernel sets all three)
     long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
+    long epoch = 0;          // moves with every call that can change what a launch bakes in (vfik_launch_epoch)
     int n_simd = 1024;       // 4 per CU of this device
     // Batches beyond one wave per SIMD may take the persistent launch (cycle_kernel PERS; VFIK_PERSISTENT=1).  Off by default:
     // same-box A/B, lean C3 launches, rounds vs persistent: 131 072 arms 10.37 / 10.71 us, 262 144 20.47 / 20.56, 524 288
@@ -119,6 +120,8 @@ struct vfik_handle {
     int slots_used = 0;
     int fast_order = 0;
     int plain = 0;  // chain / tool / weights allow the PLAIN kernel variant
+    int dhp = 0;    // ... and the chain matches a DH pattern the lean kernels are built for (vfik_kernel.h: DhPattern)
+    int dhp_allowed = 1;   // VFIK_DH_PATTERN=0: always the general DH form (tests, A/B)
     bool speed_set = false;
     // vfik_step_host / vfik_rollout_host: one device arena + one pinned host arena for every member of the call
     void* arena_dev = nullptr;
@@ -152,7 +155,9 @@ int dev_alloc(vfik_handle* h, void** p, size_t bytes, bool zero) {
 
 // A setter rewrites device state that kernels of the pipelined host path may still be reading on the
 // side streams: let those drain first (the handle's own stream is synchronised by the setters themselves).
+// (every vfik_set_* / vfik_reset_state call passes through here: the launch epoch moves with them, vfik_launch_epoch)
 int quiesce(vfik_handle* h) {
+    ++h->epoch;
     if (h->s_in) HIP_TRY(hipStreamSynchronize(h->s_in));
     if (h->s_out) HIP_TRY(hipStreamSynchronize(h->s_out));
     return VFIK_OK;
@@ -321,14 +326,15 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.kc = h->d_kconst;
     a.orders = h->d_orders;
     a.mixed = h->mixed;
+    a.dhp = a.plain ? h->dhp : 0;
 }
 
 // rewrite the device copy of the batch constants (chain + parameters); rare, synchronous
 int upload_kconst(vfik_handle* h) {
     if (!h->chain_set) return VFIK_OK;
     std::vector<char> img(vfik::kconst_bytes(h->n));
-    int plain = 0;
-    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared, &plain);
+    int plain = 0, dhp = 0;
+    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared, &plain, &dhp);
     if (!(err < 1e-9)) return fail(VFIK_E_ARG, "chain: a fixed transform is not a rigid motion (DH recomposition error %.3e)", err);
     std::memcpy(img.data() + VFIK_KCONST_REP_SAFE_OFF(h->n), &h->uni_safe, sizeof(double));   // the batch's uniform repeller pair (vfik_set_fields)
     std::memcpy(img.data() + VFIK_KCONST_REP_FORCE_OFF, &h->uni_force, sizeof(double));
@@ -336,6 +342,7 @@ int upload_kconst(vfik_handle* h) {
     HIP_TRY(hipMemcpyAsync(h->d_kconst, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->plain = plain;
+    h->dhp = h->dhp_allowed ? dhp : 0;
     return VFIK_OK;
 }
 
@@ -421,6 +428,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
     if (const char* e = std::getenv("VFIK_TWO_WAVES")) h->waves2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_UNIFORM_IMAGE")) h->uni_allowed = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_MIXED_ORDERS")) h->mixed_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("VFIK_DH_PATTERN")) h->dhp_allowed = std::atoi(e) != 0;
     if (const char* e = std::getenv("VFIK_ZERO_COPY_MAX")) h->zero_copy_max = (size_t)std::max(0L, std::atol(e));
     auto bail = [&](const char* what) { if (g_err.empty()) fail(VFIK_E_HIP, "%s failed", what); vfik_destroy(h); return (vfik_handle*)nullptr; };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
@@ -903,6 +911,14 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     const bool want_track = io->track_error != nullptr, want_dist = io->obj_dist != nullptr;
     if (want_track || want_dist) {
         if (want_dist && (!h->d_objects || h->n_objects < 1)) return fail(VFIK_E_STATE, "io->obj_dist needs vfik_set_objects");
+        // the observers' buffers are allocated at the first request: never under stream capture (an allocation there would be part of
+        // the captured work or fail it) -- a caller that captures vfik_step with observers makes one such call outside the capture first
+        if ((!a.pose && !h->d_obs_pose) || (want_track && ((!a.v6 && !h->d_obs_v6) || !h->d_track))) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(VFIK_E_STATE, "io->track_error / io->obj_dist: the observers' device buffers are allocated at the first request -- make one such vfik_step call before capturing the stream");
+            (void)hipGetLastError();
+        }
         if (!a.pose) {
             if (!h->d_obs_pose && dev_alloc(h, &h->d_obs_pose, (size_t)h->B * 16 * h->esz, true)) return VFIK_E_HIP;
             a.pose = h->d_obs_pose;
@@ -922,7 +938,7 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
         if (e != hipSuccess) return fail(VFIK_E_HIP, "track launch: %s", hipGetErrorString(e));
     }
     if (want_dist) {
-        e = vfik::launch_monitor(h->io_dtype, a.pose, h->d_objects, h->n_objects, (long)h->B * h->n_objects, io->obj_dist, stream);
+        e = vfik::launch_monitor(h->io_dtype, a.pose, h->d_objects, h->n_objects, (long)h->B * h->n_objects, io->obj_dist, stream, io->active);
         if (e != hipSuccess) return fail(VFIK_E_HIP, "monitor launch: %s", hipGetErrorString(e));
     }
     return VFIK_OK;
@@ -1346,6 +1362,10 @@ int vfik_field_path(vfik_handle* h) {
     return h->any_funnel ? 2 : 1;
 }
 
+long vfik_launch_epoch(vfik_handle* h) { return h ? h->epoch : (long)VFIK_E_ARG; }
+
+int vfik_dh_pattern(vfik_handle* h) { return h ? ((h->plain && !h->tool_per_arm && !h->d_wts) ? h->dhp : 0) : VFIK_E_ARG; }
+
 int vfik_mixed_orders(vfik_handle* h) {
     if (!h) return VFIK_E_ARG;
     return (h->fast_order >= 0 && h->mixed) ? 1 : 0;
@@ -1359,6 +1379,7 @@ int vfik_uniform_repellers(vfik_handle* h) {
 int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch) {
     if (check_handle(h)) return VFIK_E_ARG;
     if (max_batch < 0) return fail(VFIK_E_ARG, "max_batch must be >= 0");
+    ++h->epoch;
     h->sub8_max_batch = max_batch;
     h->sub8_max_batch_full = max_batch;
     h->sub8_max_batch_ns = max_batch;

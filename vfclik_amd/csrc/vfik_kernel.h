@@ -85,6 +85,18 @@ static_assert(offsetof(KConst<7>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(7) && of
 static_assert(offsetof(KConst<7>, dh) + offsetof(KConst<7>::DH, pad) == VFIK_KCONST_REP_FORCE_OFF, "KConst::dh[0].pad");
 template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KConst<NJ>) + 1023) / 1024 * 1024; };
 
+// DH patterns the lean kernels are built for (cycle_body, DHP): per joint count, bit i of
+//   SWAP: link i has a = 0 and alpha = +pi/2 EXACTLY as the kernel sees it (ca == 0, sa == 1: the host snaps |ca| < 1e-15),
+//   NONE: a = 0 and alpha = 0 (ca == 1, sa == 0),     D0: the link's z-offset d is 0.
+// Pattern 1 per joint count: the KUKA LWR 4+ (vfclik's default robot), two of them in series (BASELINE's C5), the 6-joint arm of
+// robots.py.  A chain qualifies when its own masks contain the pattern's (kconst_fill reports them; vfik_abi.cpp decides).
+template <int NJ, int DHP> struct DhPattern { static constexpr unsigned SWAP = 0, NONE = 0, D0 = 0; };
+template <> struct DhPattern<7, 1> { static constexpr unsigned SWAP = 0x3Fu, NONE = 0x40u, D0 = 0x2Au; };
+template <> struct DhPattern<14, 1> { static constexpr unsigned SWAP = 0x1FBFu, NONE = 0x2040u, D0 = 0x152Au; };
+template <> struct DhPattern<6, 1> { static constexpr unsigned SWAP = 0x1Du, NONE = 0x20u, D0 = 0x16u; };
+// the pattern id of a chain with these masks (0: none built for it)
+int dh_pattern_of(int nj, unsigned swap, unsigned none, unsigned d0);
+
 // Chains longer than this have no registers left for loop-carried state: their rollout is a sequence of
 // single-cycle launches that integrate q on the way out (vfik_abi.cpp), not the ROLL kernel variant.
 #define VFIK_ROLL_MAX_NJ 7
@@ -149,6 +161,7 @@ struct KArgs {
     // round 4: decay repellers whose INTEGER orders differ (README.old:75 documents order 20 beside the feeder's 5, object_feeder:302)
     const void* orders;          // order planes: 16 bytes per arm and plane = the decay orders of 16 slots of the compact image, one byte each
     int mixed;                   // 1: the batch's repellers do not share one order -- the straight-line path reads `orders` (MIXO kernel variants)
+    int dhp;                     // DH pattern of the chain the lean kernels may assume (DhPattern; 0: none) -- only with `plain`
 };
 
 // The per-handle device state a LEAN launch reads lives in ONE allocation with offsets that follow from (io type, joints, Bpad):
@@ -171,7 +184,7 @@ struct KLean {
 // recomposition error of the DH conversion (the caller refuses a chain above 1e-9)
 size_t kconst_bytes(int nj);
 // fill a host image of KConst<nj> at dst
-double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12, int* plain);
+double kconst_fill(int nj, void* dst, const vfik_chain& chain, const vfik_params& p, const double* tool12, int* plain, int* dhp = nullptr);
 
 // Type-erased launchers (implemented in vfik_kernel.hip).  kargs points to a KArgs<nj>.
 uint32_t supported_joints_mask();
@@ -179,7 +192,7 @@ uint32_t supported_joints_mask();
 hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream, int* sub8 = nullptr);
 hipError_t launch_probe(int io_dtype, const void* pose, const void* goal, const void* slots, int B, long Bp, int slots_used,
                         double rot_slow, double cos_slow, void* out, hipStream_t stream);
-hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream);
+hipError_t launch_monitor(int io_dtype, const void* pose, const void* frames, int O, long count, void* out, hipStream_t stream, const int* active = nullptr);
 hipError_t launch_track(int io_dtype, const void* pose, const void* v6, double* state, void* out, const int* active, int B, hipStream_t stream);
 hipError_t launch_mix(int io_dtype, const void* cmds, const double* w_dev, int K, long count, long chan_stride,
                       void* out, hipStream_t stream);

@@ -82,6 +82,8 @@ def load_library(path=None):
         "vfik_field_path": (C.c_int, [H]),
         "vfik_uniform_repellers": (C.c_int, [H]),
         "vfik_mixed_orders": (C.c_int, [H]),
+        "vfik_launch_epoch": (C.c_long, [H]),
+        "vfik_dh_pattern": (C.c_int, [H]),
         "vfik_device_bytes": (C.c_size_t, [H]),
         "vfik_host_alloc": (C.c_void_p, [H, C.c_size_t]),
         "vfik_host_free": (C.c_int, [H, C.c_void_p]),
@@ -242,6 +244,17 @@ class Engine:
     def uniform_repellers(self):
         """True when every decay repeller of the batch shares one safe distance and one force (the uniform repeller image is read)."""
         return bool(self.lib.vfik_uniform_repellers(self.h))
+
+    @property
+    def dh_pattern(self):
+        """1 when the chain matches a DH pattern the lean kernels are specialised for (include/vfik.h: vfik_dh_pattern), else 0."""
+        return int(self.lib.vfik_dh_pattern(self.h))
+
+    @property
+    def launch_epoch(self):
+        """Moves with every call that can change what a launch bakes in: a captured hipGraph of steps is valid for the epoch it was
+        captured under (include/vfik.h: vfik_launch_epoch)."""
+        return int(self.lib.vfik_launch_epoch(self.h))
 
     @property
     def mixed_orders(self):
