@@ -296,8 +296,8 @@ int vfik_mixed_orders(vfik_handle* h);
  * stay (q, the field images' CONTENT, nullspace state, external commands once allocated) needs no re-capture; the epoch moves anyway:
  * it is conservative. */
 long vfik_launch_epoch(vfik_handle* h);
-/* ABI 5, introspection.  1 when the chain set by vfik_set_chain matches a Denavit-Hartenberg pattern the lean float32-I/O kernels are
- * built for -- for 7 joints the KUKA LWR 4+ (vfclik's default robot, scripts/vfclik:42): a = 0 on every link, alpha = +-pi/2 on six,
+/* ABI 5, introspection.  1 when the chain set by vfik_set_chain matches a Denavit-Hartenberg pattern the lean float32-I/O kernels (and
+ * the eight-lanes-per-arm kernel of small batches, either I/O type) are built for -- for 7 joints the KUKA LWR 4+ (vfclik's default robot, scripts/vfclik:42): a = 0 on every link, alpha = +-pi/2 on six,
  * d = 0 on three; for 14 joints two of them in series; for 6 joints the arm of vfclik_amd/robots.py -- and launches may take the
  * variants in which those links cost no arithmetic (all-revolute chain, identity tool, unit IK weights only); 0 otherwise: every
  * chain runs, the general DH form is the fallback.  VFIK_DH_PATTERN=0 in the environment switches the specialisation off. */

@@ -825,6 +825,15 @@ def test_uniform_repeller_image(env, monkeypatch, robot, B, dt, tol, flags, nobs
     ref3 = env.oc.cycle_batch(chain, params, w["q"], F3, w["nfields"])
     eng.reset_state()
     _compare(eng.step_host(w["q"], want=want), ref3, tol, want)
+    # a repeller whose radius + safe distance is NEGATIVE (an attracting "repeller": the law allows it) cannot live in the uniform image,
+    # whose kernel clamps that sum at 0 to disarm unused slots: the compact image, same results as the oracle
+    F4 = F3.copy()
+    F4["p"][odd, min(3, nobs), 3] = np.float64(dt(-0.05))
+    eng.set_fields(F4[odd:odd + 1], w["nfields"][odd:odd + 1], first_arm=odd)
+    assert eng.field_path == 1 and not eng.uniform_repellers
+    ref4 = env.oc.cycle_batch(chain, params, w["q"], F4, w["nfields"])
+    eng.reset_state()
+    _compare(eng.step_host(w["q"], want=want), ref4, tol, want)
     eng.close()
 
 

@@ -16,7 +16,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-common="--no-cpu-baseline --rollout 0 --host-path 0"
+common="--no-cpu-baseline --rollout 0 --host-path 0 --secondary 0"
 short="--steps 40 --warmup 5 --reps 2"
 for w in $wls; do
   echo "bench $w"; timeout -k 10 300 python3 $R/bench.py --workload $w $common --launch direct > $out/bench_$w.json 2> $out/bench_$w.err || echo "bench $w failed"

@@ -245,6 +245,9 @@ void pack_fields(const vfik_field* fields, int max_fields, const int32_t* counts
                 const double sv = (double)static_cast<T>(fd.p[4]), fv = (double)static_cast<T>(fd.force);
                 if (pair_state[j] == 0) { pair_state[j] = 1; pair_safe[j] = sv; pair_force[j] = fv; }
                 else if (pair_safe[j] != sv || pair_force[j] != fv) pair_state[j] = 2;
+                // (the uniform image's kernel clamps radius + safe at 0 -- how it disarms unused slots: a repeller with a NEGATIVE sum
+                // keeps the arm, hence the batch, on the compact image)
+                if ((double)static_cast<T>(fd.p[3]) + sv < 0.0) pair_state[j] = 2;
                 {   // (non-integer or large orders send the batch to the general path: the byte is not read then)
                     const double o = fd.p[5];
                     ord[((size_t)(mr >> 4) * n_arms + j) * 16 + (mr & 15)] = (o >= 0.0 && o < 128.0 && (double)(int)o == o) ? (unsigned char)(int)o : 0;
@@ -445,7 +448,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
         const size_t sz_kc = VFIK_KCONST_SLOT(vfik::kconst_bytes(n_joints));   // (+ slack inside: the kinematics block is copied in whole 1-KiB rows)
         const size_t sz_lv = (size_t)((n_joints + 4) / 4) * h->Bpad * 4 * sizeof(float);
         const size_t sz_sf = (std::max<size_t>(1, (size_t)max_slots) + 1) / 2 * 3 * quad_plane;
-        const size_t sz_su = std::max<size_t>(1, (size_t)max_slots) * quad_plane;      // uniform image: one quad plane per slot
+        const size_t sz_su = (std::max<size_t>(1, (size_t)max_slots) + 1) * quad_plane;   // uniform image: an EMPTY plane, then one quad plane per slot
         const size_t sz_sl = std::max<size_t>(1, (size_t)max_slots) * 2 * quad_plane;  // >= 1 slot: the prefetch reads slot 0
         const size_t sz_or = (std::max<size_t>(1, (size_t)max_slots) + 15) / 16 * (size_t)h->Bpad * 16;   // order planes (zeros: order 0, force 0)
         if (dev_alloc(h, &h->d_arena, sz_goal + sz_kc + sz_lv + sz_sf + sz_su + sz_sl + sz_or, true)) return bail("alloc state arena");
@@ -465,7 +468,7 @@ vfik_handle* vfik_create(int device, int io_dtype, int n_joints, int max_slots, 
             if (io_dtype == 32) put<float>(plane, (size_t)b * 4 + 3, -std::numeric_limits<double>::infinity());
             else put<double>(plane, (size_t)b * 4 + 3, -std::numeric_limits<double>::infinity());
         }
-        for (int sidx = 0; sidx < std::max(1, max_slots); ++sidx)
+        for (int sidx = 0; sidx < std::max(1, max_slots) + 1; ++sidx)   // (plane 0 stays like this for good: the slot every out-of-range quad reads)
             if (hipMemcpyAsync(static_cast<char*>(h->d_slots_uni) + (size_t)sidx * plane.size(), plane.data(), plane.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess)
                 return bail("init uniform image");
         if (hipStreamSynchronize(h->stream) != hipSuccess) return bail("init uniform image");
@@ -703,7 +706,7 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
         HIP_TRY(hipMemcpy2DAsync(ds, pitch, slots.data(), w, w, (size_t)S * 2, hipMemcpyHostToDevice, h->stream));
         char* df = static_cast<char*>(h->d_slots_fast) + (size_t)first_arm * qb;
         HIP_TRY(hipMemcpy2DAsync(df, pitch, fast.data(), w, w, (size_t)((S + 1) / 2) * 3, hipMemcpyHostToDevice, h->stream));
-        char* du = static_cast<char*>(h->d_slots_uni) + (size_t)first_arm * qb;
+        char* du = static_cast<char*>(h->d_slots_uni) + pitch + (size_t)first_arm * qb;   // (slot m in plane m + 1)
         HIP_TRY(hipMemcpy2DAsync(du, pitch, uni.data(), w, w, (size_t)S, hipMemcpyHostToDevice, h->stream));
         char* dor = static_cast<char*>(h->d_orders) + (size_t)first_arm * 16;
         HIP_TRY(hipMemcpy2DAsync(dor, (size_t)h->Bpad * 16, ord.data(), (size_t)n_arms * 16, (size_t)n_arms * 16, (size_t)(S + 15) / 16, hipMemcpyHostToDevice, h->stream));
@@ -733,10 +736,12 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
     }
     if (!h->mixed_allowed && mixed) general = true;
     h->mixed = (!general && mixed) ? 1 : 0;
-    h->fast_order = general ? -1 : (fo < 0 ? 0 : fo);
+    h->fast_order = general ? -1 : (fo < 0 ? 5 : fo);   // (no repeller anywhere: any order >= 1 will do -- see the uniform image below)
     // one (safe distance, force) for every decay repeller of the batch?  Then the pair goes into the device constants and the lean
     // launches read the uniform image.
-    bool uni_ok = !general, have = false;
+    // (not with decay order 0: the uniform image disarms an unused slot through its magnitude, ((radius + safe) / D)^order = 0^order,
+    // which is 1 for order 0)
+    bool uni_ok = !general && h->fast_order != 0, have = false;
     double us = 0.0, uf = 0.0;
     for (int b = 0; b < h->B && uni_ok; ++b) {
         const char st = h->arm_pair_state[b];

@@ -995,8 +995,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         // number of outstanding requests is a compile-time constant for the counted waits
         // (Round 3 tried a wave-uniform fast path without the per-quad compare / select when every slot of the window is in use --
         // ~60 fewer scalar instructions a wave: C3 +1.2 % warm, +0.3 % cold, C5 +-0.1 %; scalar work is not what a lone wave waits for.)
+        // (UNI: plane 0 of the uniform image is an EMPTY slot for every arm -- radius -inf --, slot m sits in plane m + 1: a quad past the
+        // slots in use is then harmless by itself and the chunk needs no mask)
         const bool in = UNI ? idx < npre : (FASTF ? 2 * (idx / 3) < npre : (idx >> 1) < npre);
-        stage_quad<T, NTL>(slots0 + (in ? (long)idx * planeB : 0), (unsigned)armx * (unsigned)QB, dr, Stage<T>::slot_off(idx, NJ));
+        stage_quad<T, NTL>(slots0 + (in ? (long)(UNI ? idx + 1 : idx) * planeB : 0), (unsigned)armx * (unsigned)QB, dr, Stage<T>::slot_off(idx, NJ));
     };
     auto issue_slot_quad = [&](int idx) { issue_slot_quad_of(idx, arm, dreg); };
     constexpr int N_SLOT = QPC * Q16;                       // requests issued after the goal
@@ -1541,6 +1543,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                     for (int u = 0; u < PRE / 4; ++u) ow[u] = *reinterpret_cast<const unsigned*>(orow + 4 * u);
                 }
                 if constexpr (UNI) {  // a slot = one quad (x y z radius | radius = -inf: unused); safe distance and force are the batch's (KConst)
+                    // An unused slot needs no test: max(-inf + safe, 0) = 0 makes its magnitude 0 (the host admits the uniform image only
+                    // when radius + safe >= 0 for every repeller), and quads past the slots in use were requested from the image's empty
+                    // plane -- 2 operations a slot where the masked form had 6 (round 4: C3 -2 %).
                     const double usafe = kl->rep_safe, uforce = kl->dh[0].pad;
 #pragma unroll
                     for (int m = 0; m < PRE; ++m) {
@@ -1549,9 +1554,8 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                         dx[m] = v[0] - pt[0];
                         dy[m] = v[1] - pt[1];
                         dz[m] = v[2] - pt[2];
-                        const bool on = m < ncur && v[3] > -1.0e300;   // (radius -inf: a slot this arm does not use)
-                        rs[m] = on ? v[3] + usafe : 0.0;
-                        fk[m] = on ? uforce : 0.0;
+                        rs[m] = fmax(v[3] + usafe, 0.0);
+                        fk[m] = uforce;
                     }
                 } else
 #pragma unroll
@@ -1574,7 +1578,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
                     for (int idx = 0; idx < QPC; ++idx) {
                         const int m = UNI ? c0 + PRE + idx : c0 + PRE + 2 * (idx / 3);  // (first) slot of the quad
-                        const char* sm = slots0 + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
+                        const char* sm = slots0 + (m < a.slots_used ? (long)(UNI ? c0 + PRE + idx + 1 : (c0 + PRE) / 2 * 3 + idx) * planeB : 0);
                         stage_quad<T, NTL>(sm, (unsigned)arm * (unsigned)QB, dreg, Stage<T>::slot_off(idx, NJ));
                     }
                     if constexpr (MIXO) issue_orders(c0 + PRE);   // (the row's bytes of this chunk are in registers)
@@ -2070,10 +2074,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         // are contiguous and the 64 lanes of a store instruction hit 64 different places K elements apart: 61 such
         // instructions for everything vf / nullspace / debug publish cost the C3 batch 3.5 us (7 700 cycles per wave,
         // tools/stamps.py C3F).  The wave's 64 rows are ONE contiguous tile of 64 K elements: it is assembled in LDS (the
-        // goal block's rows, dead by now) and written with 16 bytes per lane, 1 KiB per instruction.  Not for LEAN launches
+        // goal block's rows, dead by now) and written with 16 bytes per lane, 1 KiB per instruction.  Not for LEAN launches of short chains
         // (seven stores in all), gated launches (a silent arm's row must stay), the batch's last partial wave, or output
         // pointers that are not 16-byte aligned: those store lane by lane.
-        const bool tiles = (LEAN == 0 || LEAN == 3) && !a.active && (arm - lanec) + 64 <= a.B;
+        // (lean launches -- one row set -- take the tile for long chains only: 14 columns are 4 tile stores instead of 14 strided ones, C5 -2.1 %;
+        // 7 columns are 2 instead of 7 and the LDS round trip costs more than they save, C3 +2.0 %, C3N +1.7 %: profiles/r04_ab_lean_tiles.txt)
+        const bool tiles = (LEAN == 0 || LEAN == 3 || (LEAN == 1 && NJ >= 10)) && !a.active && (arm - lanec) + 64 <= a.B;
         auto put_rows = [&](void* out, auto kconst, auto&& val) {   // out[arm][i] = val(i), i < K
             constexpr int K = decltype(kconst)::value;
             T* const o = static_cast<T*>(out);
@@ -2449,7 +2455,7 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
 // for.  Same arithmetic as cycle_kernel up to the order of the field sum; lane 0 of each group stores the arm's rows.
 // ------------------------------------------------------------------------------------------------
 #define VFIK_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // one wave per block: in-order LDS queue, no s_barrier needed
-template <typename T, int NJ, bool NS>
+template <typename T, int NJ, bool NS, int DHP>
 __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
     static_assert(NJ <= 8 && (!NS || NJ <= 7), "one lane per joint; the sign memory is for chains of up to 7 joints");
     const int lane = threadIdx.x & 63;
@@ -2541,21 +2547,35 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
     for (int i = 0; i < NJ; ++i) {
         Jm[i][3] = R[2]; Jm[i][4] = R[5]; Jm[i][5] = R[8];
         Jm[i][0] = p[0]; Jm[i][1] = p[1]; Jm[i][2] = p[2];
-        const double ci = cs[i], si = sn[i], di = kc->dh[i].d, ai = kc->dh[i].a, ca = kc->dh[i].ca, sa = kc->dh[i].sa;
+        const double ci = cs[i], si = sn[i];
+        // (the chain's DH pattern, as in cycle_body: links that are a renaming, links that keep their frame, links without offset)
+        const bool J_SWAP = (DhPattern<NJ, DHP>::SWAP >> i) & 1u, J_NONE = (DhPattern<NJ, DHP>::NONE >> i) & 1u, J_D0 = (DhPattern<NJ, DHP>::D0 >> i) & 1u;
         double xn[3], ym[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { xn[r] = __builtin_fma(ci, R[3 * r], xn[r]); ym[r] = __builtin_fma(ci, R[3 * r + 1], -ym[r]); }
+        if (!J_D0) {
+            const double di = kc->dh[i].d;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) p[r] = __builtin_fma(di, R[3 * r + 2], p[r]);
+            for (int r = 0; r < 3; ++r) p[r] = __builtin_fma(di, R[3 * r + 2], p[r]);
+        }
+        if (J_SWAP) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { p[r] = __builtin_fma(ai, xn[r], p[r]); R[3 * r] = xn[r]; }
-        double t1[3], t2[3];
+            for (int r = 0; r < 3; ++r) { R[3 * r] = xn[r]; R[3 * r + 1] = R[3 * r + 2]; R[3 * r + 2] = -ym[r]; }
+        } else if (J_NONE) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { t1[r] = sa * R[3 * r + 2]; t2[r] = sa * ym[r]; }
+            for (int r = 0; r < 3; ++r) { R[3 * r] = xn[r]; R[3 * r + 1] = ym[r]; }
+        } else {
+            const double ai = kc->dh[i].a, ca = kc->dh[i].ca, sa = kc->dh[i].sa;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
+            for (int r = 0; r < 3; ++r) { p[r] = __builtin_fma(ai, xn[r], p[r]); R[3 * r] = xn[r]; }
+            double t1[3], t2[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { t1[r] = sa * R[3 * r + 2]; t2[r] = sa * ym[r]; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
+        }
     }
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {  // geometric Jacobian at the flange
@@ -2772,11 +2792,11 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
 }
 
 // (entry points of the eight-lanes-per-arm kernel: the argument block alone, or the prologue's arguments as preloaded scalars in front)
-template <typename T, int NJ, bool NS>
+template <typename T, int NJ, bool NS, int DHP = 0>
 __global__ void __launch_bounds__(64) cycle_sub8_kernel(const KArgs a) {
-    cycle_sub8_body<T, NJ, NS>(a);
+    cycle_sub8_body<T, NJ, NS, DHP>(a);
 }
-template <typename T, int NJ, bool NS>
+template <typename T, int NJ, bool NS, int DHP = 0>
 __global__ void __launch_bounds__(64)
 cycle_sub8_kernel_x(const void* base, const void* q, void* qdot_out, const void* null_control, const void* slots, int B, int Bpad, int slots_used, unsigned flags,
                     const KArgs a_in) {
@@ -2784,7 +2804,7 @@ cycle_sub8_kernel_x(const void* base, const void* q, void* qdot_out, const void*
     args_from_scalars<T, NJ>(a, base, q, qdot_out, a_in.status, B, Bpad, slots_used, flags);
     a.slots = slots;
     a.null_control = null_control;   // (read up front; status is stored last and stays in the block)
-    cycle_sub8_body<T, NJ, NS>(a);
+    cycle_sub8_body<T, NJ, NS, DHP>(a);
 }
 
 // The argument block a kernel variant takes: KLean for the lean single-cycle straight-line variants, KArgs otherwise
@@ -2913,10 +2933,10 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             // (with the nullspace module the scalar entry measures 1-2 % SLOWER -- one arm 5.83 against 5.73 us, C2F 7.17 against 7.07 --
             // with or without a batch fetch of the block's other members: that variant keeps the block entry)
             if constexpr (VFIK_SCALAR_KERNARG && !NS)
-                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
+                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
                                    a.slots_used, a.flags, a);
             else
-                hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS>), g8, b8, 8 * 1024, stream, a);
+                hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, a);
             if (sub8) *sub8 = 1;
             return;
         }
@@ -3049,7 +3069,7 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     const bool ns = a.flags & VFIK_F_NULLSPACE;
     if (a.n_cycles > 0 && (!a.plain || NJ > VFIK_ROLL_MAX_NJ)) return hipErrorInvalidValue;   // (stepped by the caller: launch_cycles)
     if (a.plain) {
-        if constexpr (sizeof(T) == 4 && DhPattern<NJ, 1>::SWAP != 0) {
+        if constexpr (DhPattern<NJ, 1>::SWAP != 0) {   // (float64 I/O: only the eight-lanes kernel has pattern variants, dhp_of)
             if (a.dhp == 1) {   // the chain matches the DH pattern built for this joint count (vfik_abi.cpp: upload_kconst)
                 if (ns) launch_v<T, NJ, true, true, 1>(a, grid, blk, lds, stream, sub8);
                 else launch_v<T, NJ, false, true, 1>(a, grid, blk, lds, stream, sub8);
