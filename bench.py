@@ -156,19 +156,22 @@ def c_oracle_rate(chain, params, w, threads, budget_s=8.0):
             "sample": "%d passes over the %d-arm batch in %.1f s, C oracle (oracle/vfik_oracle.c), OpenMP" % (passes, B, dt)}
 
 
-def kernel_name(io_name, n, flags, batch, sub8, full=False):
+def kernel_name(io_name, n, flags, batch, sub8, full=False, uni=True, dhp=0):
     """The kernel a lean bench launch takes (vfik_kernel.hip, launch_v) -- as rocprofv3 names it, without spaces.
-    <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN, compile-time flags>: the bench
-    workloads are revolute chains with identity tool, unit weights, integer-order repellers and qdot_out only."""
+    <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN, compile-time flags, persistent, aux block,
+    waves per SIMD, uniform repeller image, [order planes,] DH pattern>: the bench workloads are revolute chains with identity tool,
+    unit weights, integer-order repellers and qdot_out only."""
     t = "float" if io_name == "float32" else "double"
+    ns = "true" if flags & 1 else "false"
     if sub8:
-        return "vfik::cycle_sub8_kernel<%s,%d,%s>" % (t, n, "true" if flags & 1 else "false")
-    if full:  # the per-cycle rows asked for, no per-arm option: the publishing lean variant (LEAN 3)
-        cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
-        return "vfik::cycle_kernel<%s,%d,%s,true,false,true,3,%d>" % (t, n, "true" if flags & 1 else "false", cf)
+        return "vfik::cycle_sub8_kernel%s<%s,%d,%s,%d>" % ("" if flags & 1 else "_x", t, n, ns, dhp)
+    d = dhp if t == "float" else 0   # (the lane-per-arm pattern variants exist for float32 I/O)
+    u = "true" if uni else "false"
     cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
+    if full:  # the per-cycle rows asked for, no per-arm option: the publishing lean variant (LEAN 3)
+        return "vfik::cycle_kernel_x<%s,%d,%s,true,false,true,3,%d,false,false,1,%s,false,%d>" % (t, n, ns, cf, u, d)
     # (the lean variants take their ten arguments as scalars, preloaded into SGPRs: cycle_kernel_s)
-    return "vfik::cycle_kernel_s<%s,%d,%s,true,false,true,1,%d>" % (t, n, "true" if flags & 1 else "false", cf)
+    return "vfik::cycle_kernel_s<%s,%d,%s,true,false,true,1,%d,false,false,1,%s,%d>" % (t, n, ns, cf, u, d)
 
 
 def pctl(xs, p):
@@ -680,7 +683,7 @@ def worker(args):
                          "real_bytes_frac": (traffic / (us_med * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          # <io type, joints, nullspace module, PLAIN, rollout, straight-line field path, LEAN>: the bench
                          # workloads (revolute chain, identity tool, unit weights, integer-order repellers, qdot_out only)
-                         "kernel": kernel_name(io_name, chain.n, flags, B, eng.small_batch_launches > 0, bool(extra_outs)),
+                         "kernel": kernel_name(io_name, chain.n, flags, B, eng.small_batch_launches > 0, bool(extra_outs), eng.uniform_repellers, eng.dh_pattern),
                          "algorithmic_bytes_per_cycle": bytes_per_cycle,
                          "us_per_launch_hip_events": us_med,
                          "us_per_launch_p10": pctl(us_launch, 10), "us_per_launch_p90": pctl(us_launch, 90),

@@ -90,12 +90,17 @@ template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KCons
 //   NONE: a = 0 and alpha = 0 (ca == 1, sa == 0),     D0: the link's z-offset d is 0.
 // Pattern 1 per joint count: the KUKA LWR 4+ (vfclik's default robot), two of them in series (BASELINE's C5), the 6-joint arm of
 // robots.py.  A chain qualifies when its own masks contain the pattern's (kconst_fill reports them; vfik_abi.cpp decides).
-template <int NJ, int DHP> struct DhPattern { static constexpr unsigned SWAP = 0, NONE = 0, D0 = 0; };
-template <> struct DhPattern<7, 1> { static constexpr unsigned SWAP = 0x3Fu, NONE = 0x40u, D0 = 0x2Au; };
-template <> struct DhPattern<14, 1> { static constexpr unsigned SWAP = 0x1FBFu, NONE = 0x2040u, D0 = 0x152Au; };
-template <> struct DhPattern<6, 1> { static constexpr unsigned SWAP = 0x1Du, NONE = 0x20u, D0 = 0x16u; };
+//   OFF0 / OFFPI: the joint's angle offset in the DH form is an even / odd multiple of pi (the joint angle itself enters the
+//   sin / cos, an odd multiple negates both),     BASE_I: the base frame B[0] is the identity (joint 1 starts from unit vectors).
+template <int NJ, int DHP> struct DhPattern { static constexpr unsigned SWAP = 0, NONE = 0, D0 = 0, OFF0 = 0, OFFPI = 0; static constexpr bool BASE_I = false; };
+template <> struct DhPattern<7, 1> { static constexpr unsigned SWAP = 0x3Fu, NONE = 0x40u, D0 = 0x2Au, OFF0 = 0x15u, OFFPI = 0x6Au; static constexpr bool BASE_I = true; };
+template <> struct DhPattern<14, 1> {
+    static constexpr unsigned SWAP = 0x1FBFu, NONE = 0x2040u, D0 = 0x152Au, OFF0 = 0xA95u, OFFPI = 0x356Au;
+    static constexpr bool BASE_I = true;
+};
+template <> struct DhPattern<6, 1> { static constexpr unsigned SWAP = 0x1Du, NONE = 0x20u, D0 = 0x16u, OFF0 = 0x27u, OFFPI = 0x18u; static constexpr bool BASE_I = true; };
 // the pattern id of a chain with these masks (0: none built for it)
-int dh_pattern_of(int nj, unsigned swap, unsigned none, unsigned d0);
+int dh_pattern_of(int nj, unsigned swap, unsigned none, unsigned d0, unsigned off0, unsigned offpi, bool base_identity);
 
 // Chains longer than this have no registers left for loop-carried state: their rollout is a sequence of
 // single-cycle launches that integrate q on the way out (vfik_abi.cpp), not the ROLL kernel variant.

@@ -55,6 +55,19 @@ __device__ __forceinline__ double rsqrt_1nr(double x) {
     return __builtin_fma(0.5 * y, e, y);
 }
 
+__device__ __forceinline__ double rsqrt_1nr_pos(double x) {   // ... for x > 0 known to the caller (no clamp)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+
+// 1/x from ONE Newton step on v_rcp_f64 (relative error ~1e-14, like rsqrt_1nr): the LDL^T pivots of the IK's normal matrix, whose
+// condition number is bounded by (sigma_max^2 + lambda^2) / lambda^2 ~ 1e3 -- 1e-11 in the joint velocities against a 1e-9 test bar.
+__device__ __forceinline__ double rcp_1nr(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
 // sqrt(x) and 1/sqrt(x) together (Goldschmidt from v_rsq_f64).  x = 0 gives (0, large finite).
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& root, double& inv) {
     const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
@@ -1179,21 +1192,27 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     {
         // No libm fallback: the three-part reduction keeps full accuracy to |angle| ~ 1e5 rad and degrades
         // smoothly beyond (error ~ |angle| * 1e-21); NaN / Inf propagate and are flagged VFIK_ST_NAN.
+        // (DH pattern: an offset that is an even multiple of pi is no offset, an odd one negates sine and cosine below)
+        constexpr unsigned DHP_OFFK = DhPattern<NJ, DHP>::OFF0 | DhPattern<NJ, DHP>::OFFPI;
         double ang[NJ];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) ang[i] = q[i] + klc->dh[i].off;
+        for (int i = 0; i < NJ; ++i) ang[i] = (PLAIN && ((DHP_OFFK >> i) & 1u)) ? q[i] : q[i] + klc->dh[i].off;
         // Chains of up to 8 joints go through the LDS table (C3 -2 %, C3N -3.5 %, C2 -2.5 % in same-box A/Bs).  Long
         // chains keep the table-free form: the 14-joint kernel has no registers for 28 table values on top of its
         // Jacobian and was 2-4 % SLOWER with the table, all angles at once, in two halves or inside the kinematics.
         if constexpr (TABSC) sincos_tab_n<NJ>(ang, reinterpret_cast<const char*>(klc) + (Stage<T>::tab_off(NJ) - Stage<T>::kin_off(NJ)), sn, cs);
         else sincos_fast_n<NJ>(ang, sn, cs);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+            if (PLAIN && ((DhPattern<NJ, DHP>::OFFPI >> i) & 1u)) { sn[i] = -sn[i]; cs[i] = -cs[i]; }
     }
     double R[9], p[3];
+    constexpr bool BASE_I = PLAIN && DhPattern<NJ, DHP>::BASE_I;   // the base frame is the identity: joint 1 starts from unit vectors
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R[3 * r + c] = klc->base[4 * r + c];
-        p[r] = klc->base[4 * r + 3];
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = BASE_I ? (r == c ? 1.0 : 0.0) : klc->base[4 * r + c];
+        p[r] = BASE_I ? 0.0 : klc->base[4 * r + 3];
     }
     // Jm[i] = column i of the 6 x n Jacobian (rows 0..2 linear, 3..5 angular); during the kinematics
     // it first holds the joint origin and axis.  The nullspace module later orthonormalises its ROWS in
@@ -1213,6 +1232,11 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         // (i is a constant once the loop is unrolled: the tests fold away)
         const bool J_SWAP = PLAIN && ((DHP_SWAP >> i) & 1u), J_NONE = PLAIN && ((DHP_NONE >> i) & 1u), J_D0 = PLAIN && ((DHP_D0 >> i) & 1u);
         double xn[3], ym[3];
+        if (BASE_I && i == 0) {   // R = I, p = 0: x' = (c, s, 0), y' = (-s, c, 0), p' = (0, 0, d) -- no arithmetic
+            xn[0] = ci; xn[1] = si; xn[2] = 0.0;
+            ym[0] = -si; ym[1] = ci; ym[2] = 0.0;
+            if (!J_D0) p[2] = di;
+        } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
 #pragma unroll
@@ -1220,6 +1244,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         if (!J_D0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) p[r] = __builtin_fma(di, R[3 * r + 2], p[r]);
+        }
         }
         if (J_SWAP) {          // alpha = +pi/2 (the DH factorisation keeps sin alpha >= 0): y' = z, z' = -y -- no arithmetic at all
 #pragma unroll
@@ -1438,7 +1463,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
             for (int k = 0; k < j; ++k) dj = __builtin_fma(-A[j][k], v[k], dj);
             A[j][j] = dj;
-            dinv[j] = rcp_nr(dj);
+            dinv[j] = rcp_1nr(dj);
 #pragma unroll
             for (int k = 0; k < j; ++k)  // rows below j, one k at a time: the rows are independent chains
 #pragma unroll
@@ -1586,7 +1611,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                 double di[PRE], rb[PRE], rp[PRE];
 #pragma unroll
                 for (int m = 0; m < PRE; ++m) {
-                    di[m] = fmin(rsqrt_1nr(dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m]), 1.0 / D_FLOOR);
+                    // (the sum starts from 1e-300 instead of being clamped there afterwards: one operation less a slot, the same guard
+                    // against 0 * inf when the tool sits exactly on an obstacle's centre)
+                    di[m] = fmin(rsqrt_1nr_pos(__builtin_fma(dx[m], dx[m], __builtin_fma(dy[m], dy[m], __builtin_fma(dz[m], dz[m], 1e-300)))), 1.0 / D_FLOOR);
                     rb[m] = rs[m] * di[m];
                     rp[m] = 1.0;
                 }
@@ -3161,7 +3188,7 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     memset(&c, 0, sizeof c);
     memcpy(c.base, ch.B[0], sizeof c.base);
     double phi_prev = 0.0, e_prev = 0.0, worst = 0.0;
-    unsigned m_swap = 0, m_none = 0, m_d0 = 0;   // the chain's DH pattern (vfik_kernel.h: DhPattern)
+    unsigned m_swap = 0, m_none = 0, m_d0 = 0, m_off0 = 0, m_offpi = 0;   // the chain's DH pattern (vfik_kernel.h: DhPattern)
     for (int i = 0; i < NJ; ++i) {
         const Screws s = dh_factor(ch.B[i + 1]);
         worst = std::fmax(worst, dh_recompose_error(s, ch.B[i + 1]));
@@ -3185,6 +3212,14 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
         if (!pris && c.dh[i].a == 0.0 && c.dh[i].ca == 0.0 && c.dh[i].sa == 1.0) m_swap |= 1u << i;
         if (!pris && c.dh[i].a == 0.0 && c.dh[i].ca == 1.0 && c.dh[i].sa == 0.0) m_none |= 1u << i;
         if (!pris && c.dh[i].d == 0.0) m_d0 |= 1u << i;
+        {   // an offset that is a multiple of pi: snapped to it, so that the pattern's "no offset" / "negate" is exact for this chain
+            const double kpi = off / 3.14159265358979323846;
+            const double kr = std::nearbyint(kpi);
+            if (!pris && std::fabs(kpi - kr) < 1e-12) {
+                c.dh[i].off = kr * 3.14159265358979323846;
+                if (((long)kr) % 2 == 0) m_off0 |= 1u << i; else m_offpi |= 1u << i;
+            }
+        }
         phi_prev = s.phi;
         e_prev = s.e;
         const double half = 0.5 * (ch.q_hi[i] - ch.q_lo[i]);
@@ -3219,7 +3254,12 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     for (int i = 0; i < 6; ++i) pl = pl && p.wy[i] == 1.0;
     for (int i = 0; i < NJ; ++i) pl = pl && p.wq[i] == 1.0;
     *plain = pl ? 1 : 0;
-    if (dhp) *dhp = pl ? dh_pattern_of(NJ, m_swap, m_none, m_d0) : 0;
+    bool base_i = true;
+    {
+        static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        for (int k = 0; k < 12; ++k) base_i = base_i && c.base[k] == ident[k];
+    }
+    if (dhp) *dhp = pl ? dh_pattern_of(NJ, m_swap, m_none, m_d0, m_off0, m_offpi, base_i) : 0;
     // (sin, cos)(k pi/32), k = 0 .. 63, for sincos_tab_n
     double* tab = reinterpret_cast<double*>(static_cast<char*>(dst) + KTab<NJ>::OFFSET);
     for (int k = 0; k < 64; ++k) {
@@ -3232,16 +3272,18 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
 
 }  // namespace
 
-int dh_pattern_of(int nj, unsigned swap, unsigned none, unsigned d0) {
-    unsigned ps = 0, pn = 0, pd = 0;
+int dh_pattern_of(int nj, unsigned swap, unsigned none, unsigned d0, unsigned off0, unsigned offpi, bool base_identity) {
+    unsigned ps = 0, pn = 0, pd = 0, p0 = 0, ppi = 0;
+    bool pb = false;
     switch (nj) {
-#define X(n) case n: ps = DhPattern<n, 1>::SWAP; pn = DhPattern<n, 1>::NONE; pd = DhPattern<n, 1>::D0; break;
+#define X(n) case n: ps = DhPattern<n, 1>::SWAP; pn = DhPattern<n, 1>::NONE; pd = DhPattern<n, 1>::D0; p0 = DhPattern<n, 1>::OFF0; ppi = DhPattern<n, 1>::OFFPI; pb = DhPattern<n, 1>::BASE_I; break;
         VFIK_NJ_LIST
 #undef X
         default: break;
     }
     if (ps == 0) return 0;
-    return ((swap & ps) == ps && (none & pn) == pn && (d0 & pd) == pd) ? 1 : 0;
+    // the chain's zeros must CONTAIN the pattern's (more zeros are fine: they are multiplied out); its pi offsets must be the pattern's
+    return ((swap & ps) == ps && (none & pn) == pn && (d0 & pd) == pd && (off0 & p0) == p0 && (offpi & ppi) == ppi && (!pb || base_identity)) ? 1 : 0;
 }
 
 uint32_t supported_joints_mask() {
