@@ -1019,7 +1019,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     // slot quads are requested into that wait, the remaining slot quads between the joints.
     // (long chains have two rows of constants and five q pieces in front already: nothing early there, C5 -1.3 %)
     // PERS: the first chunk's requests all go out here; the slots between the joints are the NEXT chunk's requests.
-    constexpr int EARLY_Q = PERS ? QPC : (NJ >= 10 ? 0 : 6);
+#ifndef VFIK_EARLY_Q
+#define VFIK_EARLY_Q 6            // slot quads requested into q's round trip (A/B builds: cold-state arrival order)
+#endif
+    constexpr int EARLY_Q = PERS ? QPC : (NJ >= 10 ? 0 : (VFIK_EARLY_Q < QPC ? VFIK_EARLY_Q : QPC));
     constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
     // PERS: request r of a chunk's NPF = q pieces, goal quads, slot quads, in that order (float I/O: one request a quad)
     constexpr int NPF = PERS ? NQREQ + 4 + QPC : 0;
@@ -1310,19 +1313,37 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
             for (int c = 0; c <= r; ++c) Ae[r][c] = 0.0;
         }
     }
+    // Columns of the Jacobian that are structurally sparse under the DH pattern (jzero(i, r): entry r of column i is EXACTLY zero):
+    //   * an identity base puts joint 1's axis on the base z axis through the origin: column (-p_y, p_x, 0, 0, 0, 1);
+    //   * a last link with a = 0 and alpha = 0 leaves the flange ON the last joint's axis: column (0, 0, 0, z) -- computed, its linear part
+    //     is rounding noise of size 1e-17.
+    // Every accumulation over the columns below (J J^T, J z, J^T y) skips the zero entries: 2 x 27 operations for the LWR.
+    constexpr bool J0_UNIT = BASE_I;
+    constexpr bool JL_AXIAL = PLAIN && ((DhPattern<NJ, DHP>::NONE >> (NJ - 1)) & 1u);
+    auto jzero = [&](int i, int r) { return (J0_UNIT && i == 0 && (r == 2 || r == 3 || r == 4)) || (JL_AXIAL && i == NJ - 1 && r < 3); };
     // geometric Jacobian at the flange, base frame
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         {
-            const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
-            const double cx = Jm[i][4] * dz - Jm[i][5] * dy, cy = Jm[i][5] * dx - Jm[i][3] * dz,
-                         cz = Jm[i][3] * dy - Jm[i][4] * dx;
+            double cx, cy, cz;
+            if (J0_UNIT && i == 0) {
+                cx = -p[1]; cy = p[0]; cz = 0.0;
+                Jm[i][3] = 0.0; Jm[i][4] = 0.0; Jm[i][5] = 1.0;
+            } else if (JL_AXIAL && i == NJ - 1) {
+                cx = 0.0; cy = 0.0; cz = 0.0;
+            } else {
+                const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
+                cx = Jm[i][4] * dz - Jm[i][5] * dy; cy = Jm[i][5] * dx - Jm[i][3] * dz;
+                cz = Jm[i][3] * dy - Jm[i][4] * dx;
+            }
             if constexpr (ACCJ) {
                 const double col[6] = {cx, cy, cz, Jm[i][3], Jm[i][4], Jm[i][5]};
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
+                    if (jzero(i, r)) continue;
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) Ae[ACCJ ? r : 0][c] = __builtin_fma(col[r], col[c], Ae[ACCJ ? r : 0][c]);
+                    for (int c = 0; c <= r; ++c)
+                        if (!jzero(i, c)) Ae[ACCJ ? r : 0][c] = __builtin_fma(col[r], col[c], Ae[ACCJ ? r : 0][c]);
                     if constexpr (FUSEP && !GLATE) wne[r] = __builtin_fma(col[r], zp[FUSEP ? i : 0], wne[r]);
                 }
             }
@@ -1423,8 +1444,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                 }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
+                    if (jzero(i, r)) continue;
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(PLAIN ? Jm[i][r] : t[r], Jm[i][c], A[r][c]);
+                    for (int c = 0; c <= r; ++c)
+                        if (!jzero(i, c)) A[r][c] = __builtin_fma(PLAIN ? Jm[i][r] : t[r], Jm[i][c], A[r][c]);
                     if constexpr (FUSEP && !GLATE) {
                         wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
                         if constexpr (!PLAIN) {
@@ -1946,13 +1969,14 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
-            qv[i] = Jm[i][0] * y[0];
-            if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][0], wn[0], zp[i]);
+            qv[i] = jzero(i, 0) ? 0.0 : Jm[i][0] * y[0];
+            if constexpr (FUSEP) { if (!jzero(i, 0)) zp[i] = __builtin_fma(-Jm[i][0], wn[0], zp[i]); }
         }
 #pragma unroll
         for (int r = 1; r < 6; ++r)
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
+                if (jzero(i, r)) continue;
                 qv[i] = __builtin_fma(Jm[i][r], y[r], qv[i]);
                 if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][r], wn[r], zp[i]);
             }
