@@ -443,12 +443,13 @@ __device__ void eval_slot(const RD& rd, int m, const double* Rt, const double* p
 // Every decision is taken PER LANE (per arm): which path an arm takes never depends on the other arms of its wave, so
 // its result does not depend on where in a batch it sits (wave-wide votes only decide whether a path is executed at all).
 // ------------------------------------------------------------------------------------------------
-#ifndef VFIK_EXP_N0_FROM_A
-#define VFIK_EXP_N0_FROM_A 0      // 1: the rank test's yardstick (squared row norms of J) from the diagonal of the IK's normal matrix (A/B builds)
-#endif
-template <int NJ, typename ZF>
+// ZFIRST / ZLAST: the Jacobian's first column is (x, y, 0, 0, 0, 1) / its last column (0, 0, 0, z) -- structural zeros of the chain's DH
+// pattern (cycle_body: jzero).  The Gram-Schmidt pass tracks which entries are still exactly zero (a compile-time table once the loops are
+// unrolled) and skips their terms: the last column's linear part stays zero to the end, the first column's zeros fill in at the first
+// two steps -- 44 of the module's ~550 operations.
+template <int NJ, bool ZFIRST = false, bool ZLAST = false, typename ZF>
 __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r, int& sig_r, bool& has_vec, double c0, bool jl_task,
-                                               ZF&& descent, double* qn, int& status, const double* n0_given = nullptr) {
+                                               ZF&& descent, double* qn, int& status) {
     // Orthonormal basis (rows) of the row space of J by modified Gram-Schmidt, in place in Jm:
     // afterwards I - Q^T Q is restrict(I6, J) = I - pinv(J) J (nullspace:75-79).
     // One pass: loss of orthogonality ~ eps * cond(J), far below the 1e-6 bar wherever J is usable.
@@ -456,19 +457,20 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
     // independent chains (5, 4, ... of them) that a lone wave can interleave; row by row (left-looking) the
     // same operations are one serial chain of 7-term dot products (dependent float64 ops issue every ~8
     // cycles, independent ones every ~5).  Same arithmetic, same order per row: same results.
+    bool Z[NJ][6];   // entry (column i, row r) of J is still structurally zero
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Z[i][r] = (ZFIRST && i == 0 && (r == 2 || r == 3 || r == 4)) || (ZLAST && i == NJ - 1 && r < 3);
     int rank = 0;
     double n0[6];  // squared norms of the rows of J: the rank test's yardstick
-    if (n0_given) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) n0[r] = n0_given[r];
-    } else {
+    for (int r = 0; r < 6; ++r) n0[r] = 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) n0[r] = Jm[0][r] * Jm[0][r];
+    for (int i = 0; i < NJ; ++i)
 #pragma unroll
-    for (int i = 1; i < NJ; ++i)
-#pragma unroll
-        for (int r = 0; r < 6; ++r) n0[r] = __builtin_fma(Jm[i][r], Jm[i][r], n0[r]);
-    }
+        for (int r = 0; r < 6; ++r)
+            if (!Z[i][r]) n0[r] = __builtin_fma(Jm[i][r], Jm[i][r], n0[r]);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         double n1 = 0.0;
@@ -476,7 +478,8 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
             n1 = n0[0];  // nothing has been projected out of the first row
         } else {
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) n1 += Jm[i][s] * Jm[i][s];
+            for (int i = 0; i < NJ; ++i)
+                if (!Z[i][s]) n1 += Jm[i][s] * Jm[i][s];
         }
         const bool keep = n1 > 1e-24 * n0[s] && n0[s] > 0.0;
         double n1r, n1i;
@@ -484,18 +487,24 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
         const double inv = keep ? n1i : 0.0;
         rank += keep ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) Jm[i][s] *= inv;
+        for (int i = 0; i < NJ; ++i)
+            if (!Z[i][s]) Jm[i][s] *= inv;
         double c[6];
 #pragma unroll
         for (int r = s + 1; r < 6; ++r) c[r] = 0.0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i)
 #pragma unroll
-            for (int r = s + 1; r < 6; ++r) c[r] += Jm[i][s] * Jm[i][r];
+            for (int r = s + 1; r < 6; ++r)
+                if (!Z[i][s] && !Z[i][r]) c[r] += Jm[i][s] * Jm[i][r];
 #pragma unroll
         for (int i = 0; i < NJ; ++i)
 #pragma unroll
-            for (int r = s + 1; r < 6; ++r) Jm[i][r] -= c[r] * Jm[i][s];
+            for (int r = s + 1; r < 6; ++r) {
+                if (Z[i][s]) continue;                 // nothing of row s in this column
+                if (Z[i][r]) { Jm[i][r] = -(c[r] * Jm[i][s]); Z[i][r] = false; }
+                else Jm[i][r] -= c[r] * Jm[i][s];
+            }
     }
     const int nullity = NJ - rank;
     bool advanced = false;
@@ -510,11 +519,13 @@ __device__ __forceinline__ bool nullspace_core(double (&Jm)[NJ][6], double* lv_r
 #pragma unroll
             for (int i = 0; i < NJ; ++i)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) c[r] += Jm[i][r] * x[i];
+                for (int r = 0; r < 6; ++r)
+                    if (!Z[i][r]) c[r] += Jm[i][r] * x[i];
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) x[i] -= c[r] * Jm[i][r];
+                for (int i = 0; i < NJ; ++i)
+                    if (!Z[i][r]) x[i] -= c[r] * Jm[i][r];
             double cm = fabs(c[0]);
 #pragma unroll
             for (int r = 1; r < 6; ++r) cm = fmax(cm, fabs(c[r]));
@@ -1019,8 +1030,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     // slot quads are requested into that wait, the remaining slot quads between the joints.
     // (long chains have two rows of constants and five q pieces in front already: nothing early there, C5 -1.3 %)
     // PERS: the first chunk's requests all go out here; the slots between the joints are the NEXT chunk's requests.
+    // Round 4: NO slot quad goes out early any more (until then six of them were requested into q's round trip).  With the inputs in HBM every
+    // wave's ~20 requests of the launch's first half microsecond compete for the same bandwidth -- 16.5 MB in all, 2-3 us of HBM time -- and
+    // what a wave needs FIRST (q: 1.8 MB over the batch, then the goal block) queued behind slot data it needs last: slot quads requested
+    // between the joints instead, C3 cold 5.57 -> 5.21 us (-6.5 %), three early 5.44; warm +-0 (profiles/r04_ab_early_q.txt).
 #ifndef VFIK_EARLY_Q
-#define VFIK_EARLY_Q 6            // slot quads requested into q's round trip (A/B builds: cold-state arrival order)
+#define VFIK_EARLY_Q 0            // slot quads requested into q's round trip (A/B builds)
 #endif
     constexpr int EARLY_Q = PERS ? QPC : (NJ >= 10 ? 0 : (VFIK_EARLY_Q < QPC ? VFIK_EARLY_Q : QPC));
     constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
@@ -1402,7 +1417,6 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     // Jacobian: A = Wy (J Wq^2 J^T) Wy + lambda^2 I and qdot = Wq^2 J^T (Wy y).  (Until round 3 the general variants kept
     // Sw = Wy J Wq beside J: 12 n more registers, which the 10- and 14-joint kernels and the rollouts spilled to scratch.)
     double wyv[PLAIN ? 1 : 6];
-    double adiag[6];
     auto wq2_of = [&](int i) {  // wq_i^2 of this arm
         const double wqi = wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i];
         return wqi * wqi;
@@ -1471,10 +1485,6 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                 for (int c = 0; c <= r; ++c) G[FUSEP ? r : 0][c] = A[r][c];
                 A[r][r] += HOTK(lambda2);
             }
-        }
-        if constexpr (VFIK_EXP_N0_FROM_A && PLAIN && NULLSP && NJ <= 7) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) adiag[r] = A[r][r];   // |row r of J|^2 + lambda^2
         }
         // LDL^T (unit lower L stored in A's strict lower part, d on the diagonal)
 #pragma unroll
@@ -2015,8 +2025,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
             if constexpr (!ROLL && WAVES == 2) load_null_state();
             double c0 = 0.0;
             if (a.null_control) c0 = (double)static_cast<const T*>(a.null_control)[(long)arm * VFIK_NULL_CONTROLS];
-            const bool advanced = nullspace_core<NJ>(Jm, lv_r, sig_r, has_vec, c0, (a.flags & VFIK_F_JOINT_LIMIT_TASK) != 0, jl_descent, qn, status,
-                                                     (VFIK_EXP_N0_FROM_A && PLAIN) ? adiag : nullptr);
+            const bool advanced = nullspace_core<NJ, J0_UNIT, JL_AXIAL>(Jm, lv_r, sig_r, has_vec, c0, (a.flags & VFIK_F_JOINT_LIMIT_TASK) != 0, jl_descent, qn, status);
             if constexpr (!ROLL) {
                 if (advanced && act) store_null_state();
             }
