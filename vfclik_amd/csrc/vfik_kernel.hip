@@ -952,8 +952,11 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         const char* qg = static_cast<const char*>(a.q) + (long)armx * NJ * sizeof(T);
         char* qrow = dr + Stage<T>::Q_OFF;
         constexpr int n16 = Stage<T>::q16(NJ);
-        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, 0);
+#ifndef VFIK_Q_NT
+#define VFIK_Q_NT 0               // 1: q's pieces with the non-temporal policy too (A/B builds)
+#endif
+        if (r < n16) __builtin_amdgcn_global_load_lds((GPtr)(qg + r * 16), (LPtr)(qrow + r * 1024), 16, 0, VFIK_Q_NT ? 2 : 0);
+        else __builtin_amdgcn_global_load_lds((GPtr)(qg + n16 * 16 + (r - n16) * 4), (LPtr)(qrow + n16 * 1024 + (r - n16) * 256), 4, 0, VFIK_Q_NT ? 2 : 0);
 #endif
     };
     // (Round 3 tried q's pieces FIRST, in front of the constants -- q is the one input the wave cannot start without, and with the
@@ -1038,7 +1041,15 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #define VFIK_EARLY_Q 0            // slot quads requested into q's round trip (A/B builds)
 #endif
     constexpr int EARLY_Q = PERS ? QPC : (NJ >= 10 ? 0 : (VFIK_EARLY_Q < QPC ? VFIK_EARLY_Q : QPC));
-    constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + NJ - 1) / NJ;  // slot quads requested after each joint
+#ifndef VFIK_GOAL_LATE
+#define VFIK_GOAL_LATE 0          // 1: the goal block requested behind the first joint's transform instead of in front of the kinematics (A/B builds)
+#endif
+#ifndef VFIK_SLOT_JOINT0
+#define VFIK_SLOT_JOINT0 0        // first joint behind which slot quads are requested (A/B builds)
+#endif
+    constexpr bool GOAL_LATE = VFIK_GOAL_LATE && !PERS;
+    constexpr int SJ0 = (VFIK_SLOT_JOINT0 < NJ - 1 && !PERS) ? VFIK_SLOT_JOINT0 : 0;
+    constexpr int SLOTQ_PER_JOINT = (QPC - EARLY_Q + (NJ - SJ0) - 1) / (NJ - SJ0);  // slot quads requested after each joint
     // PERS: request r of a chunk's NPF = q pieces, goal quads, slot quads, in that order (float I/O: one request a quad)
     constexpr int NPF = PERS ? NQREQ + 4 + QPC : 0;
     constexpr int PF_PER_JOINT = (NPF + NJ - 1) / NJ;
@@ -1047,8 +1058,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         else if (r < NQREQ + 4) issue_goal_quad(r - NQREQ, armx, dr);
         else issue_slot_quad_of(r - NQREQ - 4, armx, dr);
     };
+    if constexpr (!GOAL_LATE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
+        for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
+    }
     if constexpr (FUN) {  // the funnel block, right behind the goal block: the goal's wait covers it
         const char* fg = static_cast<const char*>(a.funnel);
 #pragma unroll
@@ -1089,7 +1102,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         }
     };
     if constexpr (!PERS) {
-        VFIK_WAIT_VM((4 + NFUN + EARLY_Q) * Q16 + NORD);  // constants, table, tool and q have landed (the goal, funnel, order and early slot requests may still be out)
+        VFIK_WAIT_VM(((GOAL_LATE ? 0 : 4) + NFUN + EARLY_Q) * Q16 + NORD);  // constants, table, tool and q have landed (the goal, funnel, order and early slot requests may still be out)
         STAMP(2);
         read_q();
     }
@@ -1279,9 +1292,13 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
         for (int r = 0; r < 3; ++r) { R[3 * r + 1] = __builtin_fma(ca, ym[r], t1[r]); R[3 * r + 2] = __builtin_fma(ca, R[3 * r + 2], -t2[r]); }
         }
+        if (GOAL_LATE && first && i == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) issue_goal_quad(k, arm, dreg);
+        }
 #pragma unroll
         for (int k = 0; k < SLOTQ_PER_JOINT; ++k)
-            if (first && EARLY_Q + i * SLOTQ_PER_JOINT + k < QPC) issue_slot_quad(EARLY_Q + i * SLOTQ_PER_JOINT + k);
+            if (first && i >= SJ0 && EARLY_Q + (i - SJ0) * SLOTQ_PER_JOINT + k < QPC) issue_slot_quad(EARLY_Q + (i - SJ0) * SLOTQ_PER_JOINT + k);
         if constexpr (PERS) {  // the next chunk's requests, into the other per-arm area, a few after every joint
             if (has_next) {
 #pragma unroll
