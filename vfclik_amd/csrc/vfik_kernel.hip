@@ -978,6 +978,30 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         // the sin / cos table (64 x 16 bytes) sits behind the constants, on the next 1-KiB boundary
         if constexpr (TABSC) __builtin_amdgcn_global_load_lds((GPtr)(kg + KTab<NJ>::OFFSET), (LPtr)(region + Stage<T>::tab_off(NJ)), 16, 0, 0);
     }
+    // q as ONE BLOCK per wave (round 4).  q is batch-major ([B][n]): the 64 arms of a wave own 64 n sizeof(T) CONTIGUOUS bytes -- 1 792 for
+    // seven float joints.  Requested arm by arm that was four requests (one 16-byte piece and three 4-byte pieces per lane, a lane's row not being
+    // 16-byte sized); as a block it is ceil(n sizeof(T) / 16) requests of 16 bytes per lane that land in the q area as they lie in memory, and
+    // every lane reads ITS row from there (row stride n sizeof(T): 7 dwords, odd, conflict-free).  Two requests instead of four at ~70 cycles of
+    // the issuing wave each.  The lanes fetch pieces, not rows, so this happens before the lanes past the end of the batch retire; pieces past
+    // the batch's last row are not requested.
+#ifndef VFIK_Q_BLOCK
+#define VFIK_Q_BLOCK 1            // 0: q arm by arm, as until round 3 (A/B builds)
+#endif
+    // (the lean single-cycle variants at one wave per SIMD: elsewhere the few registers of the block form tipped variants that sit at their
+    // register limit into scratch -- 12 to 130 B per lane in seven of them)
+    constexpr bool QBLK = VFIK_Q_BLOCK && !PERS && !QFIRST && !ROLL && LEAN != 0 && WAVES == 1;
+    if constexpr (QBLK) {
+        constexpr int BQ = NJ * (int)sizeof(T);              // bytes of one row
+        constexpr int NBLK = (BQ + 15) / 16;                 // requests: 64 BQ bytes in pieces of 64 x 16
+        const int w0 = arm - lane;                           // the wave's first arm
+        const int rows = (a.B - w0) < 64 ? (a.B - w0) : 64;
+        const char* qb = static_cast<const char*>(a.q) + (long)w0 * BQ + lane * 16;
+        char* qrow = dreg + Stage<T>::Q_OFF;
+#pragma unroll
+        for (int r = 0; r < NBLK; ++r)
+            if ((r * 64 + lane) * 16 < rows * BQ)
+                __builtin_amdgcn_global_load_lds((GPtr)(qb + r * 1024), (LPtr)(qrow + r * 1024), 16, 0, 0);
+    }
     if constexpr (!PERS) {
         if (arm >= a.B) return;
     }
@@ -999,7 +1023,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
         for (int k = 0; k < 2; ++k) stage_quad<T, NTL>(mg + k * planeB, (unsigned)arm * (unsigned)QB, region, Stage<T>::mixw_off(NJ) + k * Stage<T>::QSTEP);
     }
-    if constexpr (!QFIRST) {
+    if constexpr (!QFIRST && !QBLK) {
 #pragma unroll
         for (int r = 0; r < NQREQ; ++r) issue_q_piece(r, arm, dreg);
     }
@@ -1090,6 +1114,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     char* dreg_next = region;
     auto read_q = [&]() {
         const char* qrow = dreg + Stage<T>::Q_OFF;
+        if constexpr (QBLK) {   // the wave's rows as they lie in memory
+            const T* mine = reinterpret_cast<const T*>(qrow + lane * (NJ * (int)sizeof(T)));
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) q[i] = (double)mine[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             if (Q16 == 1) {
