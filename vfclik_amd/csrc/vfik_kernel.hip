@@ -2192,17 +2192,48 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
             T* const o = static_cast<T*>(out);
             if (tiles && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0) {  // wave-uniform
                 char* const tile = dreg + Stage<T>::GOAL_OFF;   // 64 x 16 elements at most: 4 QSTEP
-                T* const mine = reinterpret_cast<T*>(tile) + lanec * K;
+                // A frame's row is 64 / 128 bytes: written element by element, the lanes of a store sit 16 / 32 banks apart and
+                // land on two banks -- 16-way conflicts, 512 / 1 024 LDS cycles a tile for each of the CU's four waves (the
+                // "1 100 cycles a 16-column tile" of round 3).  Such rows go in as 16-byte quads, the quad index XORed with
+                // the row's number (bits 1-2 for 4 quads a row, bits 0-2 for 8) so that the 8 lanes of a store group cover
+                // all 32 banks; the 16-byte reads below undo the permutation and stay conflict-free (it permutes within a
+                // row).  Other widths (2, 6, 7, 10, 14 columns) are at most 2-way: element by element.
+                constexpr int QPR = K * (int)sizeof(T) / 16;   // quads of a row
+                constexpr bool SWZ = K == 16;
+                if constexpr (SWZ) {
+                    const int sw = sizeof(T) == 4 ? (lanec >> 1) & 3 : lanec & 7;
+                    char* const row = tile + lanec * (K * (int)sizeof(T));
     #pragma unroll
-                for (int i = 0; i < K; ++i) mine[i] = (T)val(i);
+                    for (int k = 0; k < QPR; ++k) {
+                        if constexpr (sizeof(T) == 4) {
+                            f4s x;
+                            x.x = (float)val(4 * k); x.y = (float)val(4 * k + 1); x.z = (float)val(4 * k + 2); x.w = (float)val(4 * k + 3);
+                            *reinterpret_cast<f4s*>(row + ((k ^ sw) * 16)) = x;
+                        } else {
+                            typedef double d2s __attribute__((ext_vector_type(2)));
+                            d2s x;
+                            x.x = (double)val(2 * k); x.y = (double)val(2 * k + 1);
+                            *reinterpret_cast<d2s*>(row + ((k ^ sw) * 16)) = x;
+                        }
+                    }
+                } else {
+                    T* const mine = reinterpret_cast<T*>(tile) + lanec * K;
+    #pragma unroll
+                    for (int i = 0; i < K; ++i) mine[i] = (T)val(i);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's rows are in LDS (in-order LDS queue; nothing may move across)
                 constexpr int PIECES = 64 * K * (int)sizeof(T) / 16;
                 char* const g = reinterpret_cast<char*>(o + (long)(arm - lanec) * K);
     #pragma unroll
                 for (int it = 0; it * 64 < PIECES; ++it) {
                     const int pc = it * 64 + lanec;
+                    int src = pc;
+                    if constexpr (SWZ) {
+                        const int r = pc / QPR;
+                        src = pc ^ (sizeof(T) == 4 ? (r >> 1) & 3 : r & 7);   // (the XOR touches the quad-in-row bits only)
+                    }
                     if (PIECES % 64 == 0 || it * 64 + 64 <= PIECES || pc < PIECES)
-                        *reinterpret_cast<f4s*>(g + (long)pc * 16) = *reinterpret_cast<const f4s*>(tile + pc * 16);
+                        *reinterpret_cast<f4s*>(g + (long)pc * 16) = *reinterpret_cast<const f4s*>(tile + src * 16);
                 }
                 asm volatile("" ::: "memory");
             } else {
