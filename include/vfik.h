@@ -299,7 +299,7 @@ long vfik_launch_epoch(vfik_handle* h);
 /* ABI 5, introspection.  1 when the chain set by vfik_set_chain matches a Denavit-Hartenberg pattern the lean float32-I/O kernels (and
  * the eight-lanes-per-arm kernel of small batches, either I/O type) are built for -- for 7 joints the KUKA LWR 4+ (vfclik's default robot, scripts/vfclik:42): a = 0 on every link, alpha = +-pi/2 on six,
  * d = 0 on three; for 14 joints two of them in series; for 6 joints the arm of vfclik_amd/robots.py -- and launches may take the
- * variants in which those links cost no arithmetic (all-revolute chain, identity tool, unit IK weights only); 0 otherwise: every
+ * variants in which those links cost no arithmetic (all-revolute chain, unit IK weights, no tool or ONE tool for the batch); 0 otherwise: every
  * chain runs, the general DH form is the fallback.  VFIK_DH_PATTERN=0 in the environment switches the specialisation off. */
 int vfik_dh_pattern(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);

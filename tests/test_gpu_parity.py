@@ -352,6 +352,27 @@ def test_tool_shared_and_per_arm_weights_and_params(env):
     _compare(got, ref, TOL64, ALL)
 
 
+@pytest.mark.parametrize("robot,dt,tol,with_tool", [("lwr", np.float32, TOL32, False), ("lwr", np.float64, TOL64, False),
+                                                    ("lwr", np.float32, TOL32, True), ("lwr", np.float64, TOL64, True),
+                                                    ("lwr_dual14", np.float32, TOL32, False), ("lwr_dual14", np.float64, TOL64, True)])
+def test_every_row_published_at_lane_per_arm_batch_sizes(env, robot, dt, tol, with_tool):
+    """Every per-cycle row of a batch above the eight-lanes limit, so that full waves assemble their output tiles in LDS (the frames'
+    16-column rows as swizzled 16-byte quads, both element sizes) and the batch's last, partial wave stores lane by lane: the
+    publishing lean variant (no tool) and the general one (tool).  vf:341-342,462-466; nullspace:180-184; debug_jointlimits:69-73."""
+    chain = getattr(env.robots, robot)()
+    B = 4096 + 3 * 64 + 5
+    w = env.synth.make_workload(chain, B, 4, seed=21, io_dtype=dt)
+    params = env.abi.default_params(flags=env.abi.F_NULLSPACE | env.abi.F_MIXER | env.abi.F_JOINT_LIMIT_TASK)
+    tool = None
+    if with_tool:
+        tool = np.eye(4)
+        tool[:3, 3] = [0.02, -0.01, 0.2]
+        tool = tool.reshape(16)
+    got, ref = _run_both(env, chain, params, w, dt, tool=tool)
+    _compare(got, ref, tol, ALL)
+    assert np.abs(got["pose"][:, 15] - 1.0).max() == 0.0 and np.abs(got["pose_nt"][:, 12:15]).max() == 0.0
+
+
 @pytest.mark.parametrize("robot,dt,tol", [("lwr", np.float64, 1e-9), ("lwr", np.float32, 2e-5), ("lwr_dual14", np.float64, 1e-9)])
 def test_ik_weights_of_each_arm(env, robot, dt, tol):
     """Every arm's vf process keeps its own 't' / 'j' weights (vf:164-179,295-309): three groups of arms with

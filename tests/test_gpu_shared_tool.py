@@ -1,0 +1,133 @@
+"""The batch's shared tool on the PLAIN kernel variants (a run-time, wave-uniform branch of those kernels): vfclik's normal state is an
+arm with a hand on it -- `set tool` of old/README.old:84, scripts/vf:321-332 -- and a tool must not send a launch to the general
+variants.  Parity with the CPU oracle for every kernel family a launch with a tool can reach: lean (qdot_out only), publishing lean
+(every per-cycle row, /pose_no_tool recomposed from the tool pose), with the aux block and with differing decay orders, the
+eight-lanes size (served by one lane per arm: that kernel has no tool), the stepped rollout, both chains, both I/O types."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL = ("qdot_vf", "qdot_null", "qdot_out", "pose", "pose_nt", "v6", "qdist", "status")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle_c
+    from vfclik_amd import _abi, engine, robots, synth
+
+    class E:
+        pass
+
+    e = E()
+    e.oc, e.abi, e.engine, e.robots, e.synth = oracle_c, _abi, engine, robots, synth
+    return e
+
+
+def _tool(rot=True):
+    t = np.eye(4)
+    t[:3, 3] = [0.02, -0.01, 0.2]   # (old/README.old:84 sets 0 0 0.2)
+    if rot:
+        c, s = np.cos(0.3), np.sin(0.3)
+        t[:3, :3] = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]) @ np.array([[1, 0, 0], [0, np.cos(0.2), -np.sin(0.2)], [0, np.sin(0.2), np.cos(0.2)]])
+    return t.reshape(16)
+
+
+def _check(got, ref, tol, keys):
+    for k in keys:
+        if k == "status":
+            assert np.array_equal(got[k], ref[k])
+            continue
+        err = np.abs(got[k].astype(np.float64) - ref[k]).max()
+        assert np.all(np.isfinite(got[k])) and err < tol, "%s: %.3e" % (k, err)
+
+
+@pytest.mark.parametrize("robot,B,nobs,dt,tol,flags,want", [
+    ("lwr", 65536, 8, np.float32, 1e-6, 0, ("qdot_out", "status")),
+    ("lwr", 65536, 8, np.float32, 1e-6, 5, ("qdot_out", "status")),
+    ("lwr", 8192 + 37, 8, np.float32, 1e-6, 7, ALL),
+    ("lwr", 8192 + 37, 4, np.float64, 1e-9, 5, ALL),
+    ("lwr", 1, 4, np.float64, 1e-9, 5, ALL),
+    ("lwr", 777, 8, np.float32, 1e-6, 5, ("qdot_out", "pose", "pose_nt", "qdist", "status")),
+    ("lwr_dual14", 65536, 16, np.float32, 1e-6, 7, ("qdot_out", "status")),
+    ("lwr_dual14", 4096 + 64 + 3, 16, np.float32, 1e-6, 7, ALL),
+    ("lwr_dual14", 4096 + 64 + 3, 8, np.float64, 1e-9, 7, ALL),
+    ("powercube6", 5000, 6, np.float32, 1e-6, 0, ALL),
+])
+def test_shared_tool_on_the_plain_variants(env, robot, B, nobs, dt, tol, flags, want):
+    chain = getattr(env.robots, robot)()
+    w = env.synth.make_workload(chain, B, nobs, seed=51, io_dtype=dt)
+    params = env.abi.default_params(flags=flags)
+    tool = _tool()
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=max(8, nobs), params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_tool(tool)
+    assert eng.field_path == 1
+    assert eng.dh_pattern == 1, "a tool must not take the chain off the DH-pattern kernels"
+    got = eng.step_host(w["q"], want=want)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=tool)
+    _check(got, ref, tol, want)
+    assert np.linalg.norm(ref["pose"][:, [3, 7, 11]] - ref["pose_nt"][:, [3, 7, 11]], axis=1).min() > 0.15   # (the tool is really on)
+    # back to no tool: the same handle, the same kernels
+    eng.set_tool(np.eye(4).reshape(16))
+    got = eng.step_host(w["q"], want=want)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"])
+    _check(got, ref, tol, want)
+    eng.close()
+
+
+def test_shared_tool_with_the_aux_block_and_differing_orders(env):
+    """The README scene (old/README.old:71-84): goalAndNormal (attractor + funnel + order-5 near-goal repeller), obstacles of order 20, a
+    tool -- straight-line field path, order planes, aux block and the tool in one launch."""
+    chain = env.robots.lwr()
+    B = 4096 + 64 + 9
+    w = env.synth.make_workload(chain, B, 5, seed=52, io_dtype=np.float32, max_fields=8)
+    F = w["fields"]
+    F["id"][:, 6], F["type"][:, 6], F["force"][:, 6] = 2, 5, 30.0
+    F["p"][:, 6, 0:3] = F["p"][:, 0, [3, 7, 11]]
+    F["p"][:, 6, 3:6] = F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 6, 6:10] = [0.15, 10.0, 0.15, 2.0]
+    F["id"][:, 7], F["type"][:, 7], F["force"][:, 7] = 3, 2, -10.0
+    F["p"][:, 7, 0:3] = F["p"][:, 0, [3, 7, 11]] - 0.05 * F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 7, 3:6] = [0.05, 0.001, 5.0]
+    F["p"][:, 1:6, 5] = 20.0
+    F["p"][:, 1:6, 3] = 0.05
+    w["nfields"][:] = 8
+    params = env.abi.default_params(flags=5)
+    tool = _tool(rot=False)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=10, params=params)
+    eng.set_fields(F, w["nfields"])
+    eng.set_tool(tool)
+    assert eng.field_path == 2 and eng.mixed_orders == 1   # (straight-line path with the aux block, order planes)
+    for want in (("qdot_out", "status"), ALL):
+        got = eng.step_host(w["q"], want=want)
+        ref = env.oc.cycle_batch(chain, params, w["q"], F, w["nfields"], tool=tool)
+        _check(got, ref, 1e-6, want)
+    eng.close()
+
+
+@pytest.mark.parametrize("robot,dt", [("lwr", np.float32), ("lwr_dual14", np.float32), ("lwr", np.float64)])
+def test_rollout_with_the_shared_tool_is_stepped(env, robot, dt):
+    """vfik_rollout with a tool: single-cycle launches of the PLAIN kernels integrating q (the in-kernel loop has no register for the tool)."""
+    chain = getattr(env.robots, robot)()
+    n = chain.n
+    B, K, h = 300, 12, 0.01
+    w = env.synth.make_workload(chain, B, 4, seed=53, io_dtype=dt)
+    params = env.abi.default_params(flags=5)
+    tool = _tool()
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_tool(tool)
+    got = eng.rollout_host(w["q"], K, h, want=("qdot_out",))
+    q = w["q"].astype(np.float64).copy()
+    states = env.oc.new_states(B, n)
+    for _ in range(K):
+        ref = env.oc.cycle_batch(chain, params, q, w["fields"], w["nfields"], tool=tool, states=states)
+        q = q + h * ref["qdot_out"]
+        if dt == np.float32:
+            q = q.astype(np.float32).astype(np.float64)
+    tol = 1e-8 if dt == np.float64 else 2e-5
+    assert np.abs(got["q"] - q).max() < tol, np.abs(got["q"] - q).max()
+    eng.close()

@@ -45,7 +45,8 @@ joints, nullspace module, DH pattern>.
 mode picks at 200 launches per region): back to back under the tracer as in the untraced run.  Launched one by one, the tracer's
 per-dispatch work makes the process host-bound and the recorded durations of the short kernels bimodal and inflated (round 3:
 `r03_trace_gaps.txt`); those one-by-one traces are kept as `%(R)s_kernel_stats_direct_{warm,cold}_<W>.csv`.  The traced means run 1-5 %%
-above the untraced launch period of the last column (every dispatch carries the tracer's completion signal and timestamps): `bench.py`
+above the untraced launch period of the last column (every dispatch carries the tracer's completion signal and timestamps; a kernel shorter
+than ~5 us is held at the tracer's own dispatch period -- the round's notes): `bench.py`
 prints the untraced HIP-event figure as `roofline.frac`, which is what its contract defines, and the traced means beside it
 (`roofline.kernel_trace`, from `profiles/kernel_trace.json`).
 

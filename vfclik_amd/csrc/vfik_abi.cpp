@@ -119,7 +119,7 @@ struct vfik_handle {
     std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
     int fast_order = 0;
-    int plain = 0;  // chain / tool / weights allow the PLAIN kernel variant
+    int plain = 0;  // chain / weights allow the PLAIN kernel variant: 1 without a tool, 2 with the batch's shared tool (a run-time branch of those kernels)
     int dhp = 0;    // ... and the chain matches a DH pattern the lean kernels are built for (vfik_kernel.h: DhPattern)
     int dhp_allowed = 1;   // VFIK_DH_PATTERN=0: always the general DH form (tests, A/B)
     bool speed_set = false;
@@ -287,7 +287,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.fast_order = h->fast_order;
     a.flags = h->params.flags;
     a.tool_stride = h->tool_per_arm ? h->Bpad : 0;
-    a.plain = (h->plain && !h->tool_per_arm && !h->d_wts) ? 1 : 0;
+    a.plain = (h->plain && !h->tool_per_arm && !h->d_wts) ? h->plain : 0;   // (2: the PLAIN kernels with the shared tool)
     a.wts = h->d_wts;
     a.q = io->q;
     a.goal = h->d_goal;
@@ -883,7 +883,7 @@ static int launch_cycles(vfik_handle* h, const vfik_io* io, int n_cycles, double
     a.clamp = clamp ? 1 : 0;
     if (n_cycles > 0 && (io->track_error || io->obj_dist))
         return fail(VFIK_E_ARG, "io->track_error / io->obj_dist are per control cycle: vfik_step only, not a rollout");
-    if (n_cycles > 0 && (h->n > VFIK_ROLL_MAX_NJ || !a.plain)) {
+    if (n_cycles > 0 && (h->n > VFIK_ROLL_MAX_NJ || a.plain != 1)) {
         // Long chains, and (round 4) chains with a tool, IK weights or prismatic joints, whose in-kernel loop spilled 12-268 B per
         // lane: the rollout is n_cycles single-cycle launches, each integrating q on its way out
         // (q ping-pongs between two device buffers; the caller's io->q is never written).  The kernel has

@@ -63,6 +63,9 @@ struct KConst {
     double jp_kp, jp_delta;  // joint P controller (joint_p_controller:55-57)
     double jl_gain;          // gain of the joint-limit task (jl_k is jl_gain / half^2 of the STATIC limits; per-cycle limits use this)
     double mix_w[VFIK_MIX_CHANNELS];
+    // shared tool frame (rows 0..2 of the 4x4; per-arm tools are a device array).  In the rows every wave copies to LDS: with the inputs
+    // cold a scalar load from the tail of the block is an HBM round trip of its own (measured on a flag there: C3 +7 %, profiles/r04_ab_tool.txt)
+    double tool[12];
     double q_lo[NJ];
     double q_hi[NJ];
     double q_mid[NJ];     // (lo + hi) / 2
@@ -70,10 +73,9 @@ struct KConst {
     double jl_k[NJ];      // jl_gain / half^2
     double wq[NJ];
     double wy[6];
-    double tool[12];  // shared tool frame (rows 0..2 of the 4x4); per-arm tools are a device array
     unsigned prismatic_mask;
     unsigned pad0;
-    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4 + 10 + VFIK_MIX_CHANNELS) * 8;  // through mix_w: the block every wave copies to LDS
+    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4 + 10 + VFIK_MIX_CHANNELS + 12) * 8;  // through tool: the block every wave copies to LDS
     static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
 // The device image of the constants is KConst<NJ> padded to a multiple of 1 KiB, then the 1-KiB sin / cos table
@@ -83,6 +85,7 @@ struct KConst {
 #define VFIK_KCONST_REP_SAFE_OFF(nj) ((12 + 10 * (nj) + 3) * 8)
 static_assert(offsetof(KConst<7>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(7) && offsetof(KConst<14>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(14), "KConst::rep_safe");
 static_assert(offsetof(KConst<7>, dh) + offsetof(KConst<7>::DH, pad) == VFIK_KCONST_REP_FORCE_OFF, "KConst::dh[0].pad");
+static_assert(offsetof(KConst<7>, tool) + 96 == KConst<7>::KIN_BYTES && offsetof(KConst<14>, tool) + 96 == KConst<14>::KIN_BYTES, "KConst::tool closes the LDS-copied block");
 template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KConst<NJ>) + 1023) / 1024 * 1024; };
 
 // DH patterns the lean kernels are built for (cycle_body, DHP): per joint count, bit i of
@@ -114,7 +117,7 @@ struct KArgs {
                       // decay order (what object_feeder sends for point obstacles); -1: general path
     unsigned flags;
     int tool_stride;  // 0: one tool for the batch (KConst::tool); else per-arm tool quads ([3][Bpad])
-    int plain;        // 1: launch the PLAIN kernel variant (see vfik_kernel.hip)
+    int plain;        // 1: launch the PLAIN kernel variant (see vfik_kernel.hip); 2: PLAIN with the batch's shared tool (KConst::tool_on)
     int block;        // threads per block of the launch (read from here: blockDim.x costs its own scalar load)
     const void* q;
     const void* goal;

@@ -25,6 +25,15 @@
 #include <type_traits>
 
 namespace vfik {
+#define VFIK_CAT2(a, b) a##b
+#define VFIK_CAT(a, b) VFIK_CAT2(a, b)
+// Chains of VFIK_HEAVY_MIN_NJ joints or more: the non-lean single-cycle variants are an object of their own (-DVFIK_HEAVY_PART; launch_v)
+#ifndef VFIK_HEAVY_MIN_NJ
+#define VFIK_HEAVY_MIN_NJ 12
+#endif
+#if defined(VFIK_ONLY_NJ) && VFIK_ONLY_NJ >= VFIK_HEAVY_MIN_NJ
+void VFIK_CAT(launch_heavy_nj, VFIK_ONLY_NJ)(int io_dtype, bool ns, bool plain, bool fastf, const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream);
+#endif
 namespace {
 
 constexpr double EPS_LEN = 1e-12;  // lengths below this are zero (unit vector := 0)
@@ -664,7 +673,7 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int q16(int nj) { return qbytes(nj) / 16; }
     __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
-    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4 + 10 + VFIK_MIX_CHANNELS) * 8 + 1023) / 1024; }  // = KConst<nj>::KIN_ROWS
+    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4 + 10 + VFIK_MIX_CHANNELS + 12) * 8 + 1023) / 1024; }  // = KConst<nj>::KIN_ROWS
     __host__ __device__ static constexpr int kin_off(int nj) { return Q_OFF + qregion(nj); }
     __host__ __device__ static constexpr int tab_off(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }  // sin / cos table, 1 KiB
     __host__ __device__ static constexpr int lean_bytes(int nj) { return tab_off(nj) + 1024; }
@@ -856,6 +865,13 @@ template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, in
 __device__ __forceinline__ void
 cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, KLean, KArgs>::type& a_in) {
     static_assert(DHP == 0 || (PLAIN && FASTF && !ROLL && !PERS && (LEAN == 1 || LEAN == 3) && sizeof(T) == 4), "DHP: the lean single-cycle straight-line float variants");
+    // DHP bit 0: the chain's DH pattern (DhPattern<NJ, 1>); bit 1 (TOOLC): ONE tool for the whole batch, applied by the PLAIN kernel --
+    // vfclik's normal state is an arm with a hand on it (`set tool`, old/README.old:84; vf:321-332), and until round 4 any tool sent the
+    // launch to the general variants: C3 4.5 -> 8.0 us, C3N 6.6 -> 10.6 (profiles/r04_tool_cost.txt).  A compile-time property like the
+    // pattern: as a run-time (wave-uniform) branch of the PLAIN kernels it cost every launch WITHOUT a tool 1-2 % (two more basic blocks in the
+    // straight-line code; profiles/r04_ab_tool.txt).
+    constexpr int DHPAT = DHP & 1;
+    constexpr bool TOOLC = (DHP & 2) != 0;
     static_assert(!MIXO || (FASTF && PLAIN && !ROLL && !PERS && !UNI && WAVES == 1 && (LEAN == 1 || LEAN == 3)), "MIXO: the lean single-cycle straight-line variants");
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
@@ -910,7 +926,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     int chunk = PERS ? (int)blockIdx.x : 0;
     int arm = PERS ? chunk * 64 + (int)threadIdx.x : (int)(blockIdx.x * a.block + threadIdx.x);
     const long Bs = a.B;
-    constexpr unsigned DHP_SWAP = DhPattern<NJ, DHP>::SWAP, DHP_NONE = DhPattern<NJ, DHP>::NONE, DHP_D0 = DhPattern<NJ, DHP>::D0;
+    constexpr unsigned DHP_SWAP = DhPattern<NJ, DHPAT>::SWAP, DHP_NONE = DhPattern<NJ, DHPAT>::NONE, DHP_D0 = DhPattern<NJ, DHPAT>::D0;
     constexpr bool TABSC = NJ <= 8;  // sin / cos through the LDS table (sincos_tab_n)
     constexpr bool NTL = NJ >= VFIK_NT_MIN_NJ;   // non-temporal policy for the per-arm input planes (stage_quad)
     // batch constants through the constant address space: always scalar loads
@@ -1102,7 +1118,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 
     // The members of the argument block the rest of the cycle needs, in one batch of scalar loads behind the requests (cycle_kernel_x:
     // left alone, the compiler fetches each where it is first used -- a round trip to the kernarg segment every time)
-    if constexpr (VFIK_SCALAR_KERNARG && !SmallArgs<LEAN, ROLL, FASTF, MIXO>::value)
+    // (not in the non-lean variants of the long chains: 34 scalar registers pinned from here to the epilogue spill to vector lanes in kernels
+    // that have no vector register to spare -- part of what took their scratch away, profiles/r04_ab_experiments.md C)
+    if constexpr (VFIK_SCALAR_KERNARG && !SmallArgs<LEAN, ROLL, FASTF, MIXO>::value && !(LEAN == 0 && NJ >= 12))
         asm volatile("" ::"s"(a.null_control), "s"(a.qdot_vf), "s"(a.qdot_null), "s"(a.pose), "s"(a.pose_nt), "s"(a.v6), "s"(a.qdist), "s"(a.goal_dist),
                      "s"(a.status), "s"(a.q_out), "s"(a.ext), "s"(a.q_ref), "s"(a.q_cmded), "s"(a.q_lo), "s"(a.q_hi), "s"(a.q_ref_out), "s"(a.wts));
     STAMP(1);
@@ -1254,7 +1272,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         // No libm fallback: the three-part reduction keeps full accuracy to |angle| ~ 1e5 rad and degrades
         // smoothly beyond (error ~ |angle| * 1e-21); NaN / Inf propagate and are flagged VFIK_ST_NAN.
         // (DH pattern: an offset that is an even multiple of pi is no offset, an odd one negates sine and cosine below)
-        constexpr unsigned DHP_OFFK = DhPattern<NJ, DHP>::OFF0 | DhPattern<NJ, DHP>::OFFPI;
+        constexpr unsigned DHP_OFFK = DhPattern<NJ, DHPAT>::OFF0 | DhPattern<NJ, DHPAT>::OFFPI;
         double ang[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) ang[i] = (PLAIN && ((DHP_OFFK >> i) & 1u)) ? q[i] : q[i] + klc->dh[i].off;
@@ -1265,10 +1283,10 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         else sincos_fast_n<NJ>(ang, sn, cs);
 #pragma unroll
         for (int i = 0; i < NJ; ++i)
-            if (PLAIN && ((DhPattern<NJ, DHP>::OFFPI >> i) & 1u)) { sn[i] = -sn[i]; cs[i] = -cs[i]; }
+            if (PLAIN && ((DhPattern<NJ, DHPAT>::OFFPI >> i) & 1u)) { sn[i] = -sn[i]; cs[i] = -cs[i]; }
     }
     double R[9], p[3];
-    constexpr bool BASE_I = PLAIN && DhPattern<NJ, DHP>::BASE_I;   // the base frame is the identity: joint 1 starts from unit vectors
+    constexpr bool BASE_I = PLAIN && DhPattern<NJ, DHPAT>::BASE_I;   // the base frame is the identity: joint 1 starts from unit vectors
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -1352,7 +1370,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     constexpr bool FUSEP = NULLSP && NJ >= 8;
     // ... except with IK weights or a tool (general variant), or on the general field path: the undamped Gram matrix G = J J^T and J z are then accumulated in a
     // pass of their own AFTER the IK's solve, when the weighted normal matrix is dead -- both matrices live at once spill
-    constexpr bool GLATE = FUSEP && (!PLAIN || (!FASTF && sizeof(T) == 4));  // (float64 I/O, PLAIN, general path: 120 B of scratch without it, 108 with -- and slower)
+    // (float64 I/O, PLAIN, general path: 120 B of scratch without it, 108 with -- and slower; the non-lean float variant of 12+ joints on
+    // the general path: 60 B with it, none without, under the flags that object is built with -- Makefile, HEAVY)
+    constexpr bool GLATE = FUSEP && (!PLAIN || (!FASTF && sizeof(T) == 4 && !(LEAN == 0 && NJ >= 12)));
     double zp[FUSEP ? NJ : 1];
     // ZLATE (float64 I/O, GLATE): the task's direction is formed where it is used, behind the IK's solve -- 2 n registers less through
     // field and IK (152 -> 56, 128 -> 32 B of scratch; the float variants got WORSE with it, 76 -> 128, and keep the early form)
@@ -1381,7 +1401,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     //     is rounding noise of size 1e-17.
     // Every accumulation over the columns below (J J^T, J z, J^T y) skips the zero entries: 2 x 27 operations for the LWR.
     constexpr bool J0_UNIT = BASE_I;
-    constexpr bool JL_AXIAL = PLAIN && ((DhPattern<NJ, DHP>::NONE >> (NJ - 1)) & 1u);
+    constexpr bool JL_AXIAL = PLAIN && ((DhPattern<NJ, DHPAT>::NONE >> (NJ - 1)) & 1u);
     auto jzero = [&](int i, int r) { return (J0_UNIT && i == 0 && (r == 2 || r == 3 || r == 4)) || (JL_AXIAL && i == NJ - 1 && r < 3); };
     // geometric Jacobian at the flange, base frame
 #pragma unroll
@@ -1425,11 +1445,25 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     STAMP(3);
     // ---------------- A4: tool offset (vf:321-332) --------------------------------------------
     double Rt[9], pt[3], rr[3];
-    if (PLAIN) {  // identity tool: the tool pose is the flange pose
+    // (TOOLC: the batch's shared tool on the PLAIN kernel.  The flange frame dies here either way: the point shift of the twist (below)
+    // and /pose_no_tool (epilogue) are formed from the tool pose and the tool's constants.)
+    if (PLAIN) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rt[k] = R[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { pt[k] = p[k]; rr[k] = 0.0; }
+        if constexpr (TOOLC) {
+            double tl[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tl[k] = HOTK(tool[k]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double x = Rt[3 * r], y = Rt[3 * r + 1], z = Rt[3 * r + 2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Rt[3 * r + c] = x * tl[c] + y * tl[4 + c] + z * tl[8 + c];
+                pt[r] += x * tl[3] + y * tl[7] + z * tl[11];
+            }
+        }
     } else {
         double tl[12];
         if (a.tool_stride) {
@@ -1933,6 +1967,18 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     tw[0] = PLAIN ? v[0] : v[0] + (w[1] * rr[2] - w[2] * rr[1]);
     tw[1] = PLAIN ? v[1] : v[1] + (w[2] * rr[0] - w[0] * rr[2]);
     tw[2] = PLAIN ? v[2] : v[2] + (w[0] * rr[1] - w[1] * rr[0]);
+    if constexpr (PLAIN) {
+        if constexpr (TOOLC) {  // p_ee - p_tip = -R t = -Rt (Rtool^T t): from the tool pose, so that nothing of the flange frame lives through the field
+            double c3[3], r3[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c3[j] = HOTK(tool[j]) * HOTK(tool[3]) + HOTK(tool[4 + j]) * HOTK(tool[7]) + HOTK(tool[8 + j]) * HOTK(tool[11]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) r3[r] = -(Rt[3 * r] * c3[0] + Rt[3 * r + 1] * c3[1] + Rt[3 * r + 2] * c3[2]);
+            tw[0] += w[1] * r3[2] - w[2] * r3[1];
+            tw[1] += w[2] * r3[0] - w[0] * r3[2];
+            tw[2] += w[0] * r3[1] - w[1] * r3[0];
+        }
+    }
     tw[3] = w[0]; tw[4] = w[1]; tw[5] = w[2];
 
     // ---------------- A7: weighted damped least squares (vf:461) -------------------------------
@@ -2199,7 +2245,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                 // all 32 banks; the 16-byte reads below undo the permutation and stay conflict-free (it permutes within a
                 // row).  Other widths (2, 6, 7, 10, 14 columns) are at most 2-way: element by element.
                 constexpr int QPR = K * (int)sizeof(T) / 16;   // quads of a row
-                constexpr bool SWZ = K == 16;
+                constexpr bool SWZ = K == 16 && !ROLL;   // (a rollout publishes once per launch, and its variants have no register to spare: 12-228 B of scratch with the quads)
                 if constexpr (SWZ) {
                     const int sw = sizeof(T) == 4 ? (lanec >> 1) & 3 : lanec & 7;
                     char* const row = tile + lanec * (K * (int)sizeof(T));
@@ -2288,6 +2334,27 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                     for (int c = 0; c < 3; ++c) Rf[3 * r + c] = Rt[3 * r] * tl[4 * c] + Rt[3 * r + 1] * tl[4 * c + 1] + Rt[3 * r + 2] * tl[4 * c + 2];
                 put_rows(a.pose_nt, std::integral_constant<int, 16>(), [&](int i) {
                     return i < 12 ? ((i & 3) == 3 ? pt[i >> 2] + rr[i >> 2] : Rf[3 * (i >> 2) + (i & 3)]) : (i == 15 ? 1.0 : 0.0);
+                });
+            } else if constexpr (PLAIN) {
+                // (the tool pose IS the flange pose without a tool; with the batch's shared tool -- TOOLC -- the flange frame is recomposed,
+                // R = Rt Rtool^T and p = pt - R t)
+                double Rf[9], pf[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rf[k] = Rt[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pf[k] = pt[k];
+                if constexpr (TOOLC) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            Rf[3 * r + c] = Rt[3 * r] * HOTK(tool[4 * c]) + Rt[3 * r + 1] * HOTK(tool[4 * c + 1]) + Rt[3 * r + 2] * HOTK(tool[4 * c + 2]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) pf[r] = pt[r] - (Rf[3 * r] * HOTK(tool[3]) + Rf[3 * r + 1] * HOTK(tool[7]) + Rf[3 * r + 2] * HOTK(tool[11]));
+                }
+                put_rows(a.pose_nt, std::integral_constant<int, 16>(), [&](int i) {
+                    return i < 12 ? ((i & 3) == 3 ? pf[i >> 2] : Rf[3 * (i >> 2) + (i & 3)]) : (i == 15 ? 1.0 : 0.0);
                 });
             } else {
                 put_rows(a.pose_nt, std::integral_constant<int, 16>(), [&](int i) {
@@ -3041,6 +3108,53 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.active && !a.q_lo &&
                !a.q_ref_out;
     lean = lean_any && fastf;
+    if constexpr (PL) {
+        if (a.plain == 2) {
+            // ONE tool for the batch (`set tool`, old/README.old:84): the lean and the publishing-lean single-cycle float32 launches on
+            // the straight-line path -- what the default process set asks of an array caller and of ControlCycleBatch -- have PLAIN
+            // variants that apply it (cycle_body, TOOLC = DHP bit 1; run-time flags; with the uniform image, the aux block, the order
+            // planes), for the chain's DH pattern where one is built for the joint count.  Every other launch with a tool (float64 I/O,
+            // a rollout, per-arm options, the general field path, a chain off its pattern) takes the general variants, as until round 4.
+            constexpr bool CAP = sizeof(T) == 4 && DHP == (DhPattern<NJ, 1>::SWAP != 0 ? 1 : 0);
+            if constexpr (CAP) {
+                constexpr int DT = DHP | 2;
+                const bool lean1 = lean && !a.q_out && a.n_cycles == 0;
+                const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
+                                   !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
+                if (lean1 || lean3) {
+                    if (mixo) {
+                        const dim3 g64((unsigned)((a.B + 63) / 64)), b64(64);
+                        size_t lds_m = (long)g64.x <= (long)a.n_simd ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);
+                        if (fun) lds_m = std::max(lds_m, (size_t)(Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
+                        lds_m += 1024;
+                        a.block = 64;
+#define VFIK_LAUNCH_MT(LEANV, FUNV)                                                                                                         \
+    hipLaunchKernelGGL((cycle_kernel_m<T, NJ, NS, LEANV, FUNV, DT>), g64, b64, lds_m, stream, (const void*)a.arena, a.q, a.qdot_out, a.active, a.orders, a.B, \
+                       a.Bpad, a.slots_used, a.flags, a)
+                        if (lean1 && fun) VFIK_LAUNCH_MT(1, true);
+                        else if (lean1) VFIK_LAUNCH_MT(1, false);
+                        else if (fun) VFIK_LAUNCH_MT(3, true);
+                        else VFIK_LAUNCH_MT(3, false);
+#undef VFIK_LAUNCH_MT
+                        return;
+                    }
+                    const size_t lds_funt = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
+                    if (lean1) {
+                        if (fun) launch_lean<T, NJ, NS, PL, -1, false, true, 1, false, DT>(a, grid, blk, lds_funt, stream);
+                        else if (uni) launch_lean<T, NJ, NS, PL, -1, false, false, 1, true, DT>(a, grid, blk, lds_lean, stream);
+                        else launch_lean<T, NJ, NS, PL, -1, false, false, 1, false, DT>(a, grid, blk, lds_lean, stream);
+                    } else {
+                        if (fun) launch_full<T, NJ, NS, PL, false, true, 3, -1, false, true, false, false, DT>(a, grid, blk, lds_funt, stream);
+                        else if (uni) launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, true, false, DT>(a, grid, blk, lds_lean, stream);
+                        else launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, false, false, DT>(a, grid, blk, lds_lean, stream);
+                    }
+                    return;
+                }
+            }
+            launch_v<T, NJ, NS, false, 0>(a_in, grid, blk, lds, stream, sub8);
+            return;
+        }
+    }
     // In-kernel rollouts (ROLL) exist for PLAIN chains of up to 7 joints; with a tool, IK weights or prismatic joints the loop-carried
     // state no longer fits the registers (12-268 B of scratch per lane until round 3) and the rollout is stepped by the host side
     // (vfik_abi.cpp, launch_cycles), as for the long chains.
@@ -3192,20 +3306,37 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             return;
         }
     }
+    // The non-lean single-cycle variants.  Those of the long chains sit at the register file's limit (512 per lane, the Jacobian alone
+    // is 168) and are compiled as an object of their own with its own scheduling and allocation flags (Makefile, HEAVY): with the
+    // flags that suit the lean kernels five of them spilled 12-128 B per lane.
+#if defined(VFIK_ONLY_NJ) && VFIK_ONLY_NJ >= VFIK_HEAVY_MIN_NJ && !defined(VFIK_HEAVY_PART)
+    VFIK_CAT(launch_heavy_nj, VFIK_ONLY_NJ)(sizeof(T) == 4 ? 32 : 64, NS, PL, fastf, a, grid, blk, lds, stream);
+#else
     if (fastf) launch_full<T, NJ, NS, PL, false, true, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
     else launch_full<T, NJ, NS, PL, false, false, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
+#endif
 }
 
 template <typename T, int NJ>
 hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     KArgs a = a0;
     // (VFIK_BLOCK is a tuning knob: a block's waves must fit the CU's 160 KB of LDS with their regions)
-    while (block > 64 && (size_t)(block / 64) * Stage<T>::bytes(NJ) > 160u * 1024u) block -= 64;
+    // A full region that does not fit the CU four times (float64 I/O from 10 joints on: 42-44 KB) would leave one SIMD of every CU idle
+    // and run a 65 536-arm launch in two rounds.  Such launches go as one wave per block, each block asking for the part of the region
+    // its options use: the rows of a per-arm tool and of per-arm mixer weights are the region's tail (14 joints, float64: 34 of 44 KB
+    // without them, four blocks per CU again -- 34.3 -> 17 us with a shared tool, profiles/r04_heavy_variants.txt).
+    size_t lds;
+    if (4 * (size_t)Stage<T>::bytes(NJ) > 160u * 1024u) {
+        block = 64;
+        lds = (a.tool_stride || a.mixw) ? Stage<T>::bytes(NJ) : Stage<T>::tool_off(NJ);
+    } else {
+        while (block > 64 && (size_t)(block / 64) * Stage<T>::bytes(NJ) > 160u * 1024u) block -= 64;
+        lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
+    }
     a.block = block;
     const dim3 grid((a.B + block - 1) / block), blk(block);
-    const size_t lds = (size_t)(block / 64) * Stage<T>::bytes(NJ);
     const bool ns = a.flags & VFIK_F_NULLSPACE;
-    if (a.n_cycles > 0 && (!a.plain || NJ > VFIK_ROLL_MAX_NJ)) return hipErrorInvalidValue;   // (stepped by the caller: launch_cycles)
+    if (a.n_cycles > 0 && (a.plain != 1 || NJ > VFIK_ROLL_MAX_NJ)) return hipErrorInvalidValue;   // (stepped by the caller: launch_cycles; a tool too -- the rollout variants have no register to spare for it)
     if (a.plain) {
         if constexpr (DhPattern<NJ, 1>::SWAP != 0) {   // (float64 I/O: only the eight-lanes kernel has pattern variants, dhp_of)
             if (a.dhp == 1) {   // the chain matches the DH pattern built for this joint count (vfik_abi.cpp: upload_kconst)
@@ -3229,11 +3360,28 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
 // count with -DVFIK_ONLY_NJ=<n> (the kernels of that n, in parallel make jobs) and once with
 // -DVFIK_DISPATCH (launch dispatch, mixer kernel, host-side constant preparation).
 #ifdef VFIK_ONLY_NJ
-#define VFIK_CAT2(a, b) a##b
-#define VFIK_CAT(a, b) VFIK_CAT2(a, b)
+#ifdef VFIK_HEAVY_PART
+// -DVFIK_ONLY_NJ=<n> -DVFIK_HEAVY_PART: the non-lean single-cycle variants of a long chain, and nothing else
+void VFIK_CAT(launch_heavy_nj, VFIK_ONLY_NJ)(int io_dtype, bool ns, bool plain, bool fastf, const KArgs& a, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
+#define VFIK_HEAVY(T, NS, PL)                                                                                                      \
+    do {                                                                                                                            \
+        if (fastf) launch_full<T, VFIK_ONLY_NJ, NS, PL, false, true, 0, -1, false, false, false, false, 0>(a, grid, blk, lds, stream);  \
+        else launch_full<T, VFIK_ONLY_NJ, NS, PL, false, false, 0, -1, false, false, false, false, 0>(a, grid, blk, lds, stream);       \
+    } while (0)
+    if (io_dtype == 32) {
+        if (ns) { if (plain) VFIK_HEAVY(float, true, true); else VFIK_HEAVY(float, true, false); }
+        else { if (plain) VFIK_HEAVY(float, false, true); else VFIK_HEAVY(float, false, false); }
+    } else {
+        if (ns) { if (plain) VFIK_HEAVY(double, true, true); else VFIK_HEAVY(double, true, false); }
+        else { if (plain) VFIK_HEAVY(double, false, true); else VFIK_HEAVY(double, false, false); }
+    }
+#undef VFIK_HEAVY
+}
+#else
 hipError_t VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ)(int io_dtype, const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
     return io_dtype == 32 ? launch_t<float, VFIK_ONLY_NJ>(kargs, block, stream, sub8) : launch_t<double, VFIK_ONLY_NJ>(kargs, block, stream, sub8);
 }
+#endif
 }  // namespace vfik
 #else  // VFIK_DISPATCH
 
@@ -3358,13 +3506,16 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.jp_kp = p.jp_kp;
     c.jp_delta = p.jp_delta;
     c.jl_gain = p.jl_gain;
-    // PLAIN variant of the kernel: revolute joints only, no trailing screw, identity tool, unit weights
+    // PLAIN variant of the kernel: revolute joints only, no trailing screw, unit weights.  *plain: 0 general variants, 1 PLAIN without a
+    // tool, 2 PLAIN with the batch's shared tool (the lean float32 kernels have variants that apply it -- cycle_body, TOOLC --, every other
+    // launch with a tool takes the general variants: launch_v).
     bool pl = c.prismatic_mask == 0 && c.tail_c == 1.0 && c.tail_s == 0.0 && c.tail_e == 0.0;
     static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    for (int k = 0; k < 12; ++k) pl = pl && tool12[k] == ident[k];
+    bool tool_ident = true;
+    for (int k = 0; k < 12; ++k) tool_ident = tool_ident && tool12[k] == ident[k];
     for (int i = 0; i < 6; ++i) pl = pl && p.wy[i] == 1.0;
     for (int i = 0; i < NJ; ++i) pl = pl && p.wq[i] == 1.0;
-    *plain = pl ? 1 : 0;
+    *plain = pl ? (tool_ident ? 1 : 2) : 0;
     bool base_i = true;
     {
         static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
