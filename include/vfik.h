@@ -78,7 +78,10 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p);
  * for arms [first_arm, first_arm + n_arms).  vfik_set_params.speed_scale writes one value to all arms. */
 int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double* values);
 
-/* /tool (vf:321-326): 16 doubles row-major, shared by the batch (per_arm = 0) or tool16[B][16]. */
+/* /tool (vf:321-326): 16 doubles row-major, shared by the batch (per_arm = 0) or tool16[B][16].  ONE tool for the batch keeps the
+ * launches of an all-revolute chain with unit IK weights on the kernels built for such chains (the lean and publishing-lean float32-I/O
+ * variants apply it themselves); per-arm tools take the general variants.  A per-arm array whose rows are all equal IS a
+ * shared tool and is stored as one (with the values rounded to the I/O type, as the per-arm image would hold them). */
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
 
 /* Field sets of arms [first_arm, first_arm + n_arms): the result of the add/remove bookkeeping of

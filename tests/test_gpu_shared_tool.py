@@ -131,3 +131,29 @@ def test_rollout_with_the_shared_tool_is_stepped(env, robot, dt):
     tol = 1e-8 if dt == np.float64 else 2e-5
     assert np.abs(got["q"] - q).max() < tol, np.abs(got["q"] - q).max()
     eng.close()
+
+
+def test_equal_per_arm_tools_are_the_shared_tool(env):
+    """What a port-level caller does: every arm's /tool bottle forwarded as a per-arm array (vf:321-326).  All rows equal = the batch's
+    shared tool: the launch stays on the DH-pattern kernels, and the results are those of the per-arm image (values rounded to float32)."""
+    chain = env.robots.lwr()
+    B = 5000
+    w = env.synth.make_workload(chain, B, 8, seed=54, io_dtype=np.float32)
+    params = env.abi.default_params(flags=5)
+    tool = _tool()
+    eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_tool(np.tile(tool, (B, 1)), per_arm=True)
+    assert eng.dh_pattern == 1
+    got = eng.step_host(w["q"], want=ALL)
+    t32 = tool.astype(np.float32).astype(np.float64)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=t32)
+    _check(got, ref, 1e-6, ALL)
+    tools = np.tile(tool, (B, 1))
+    tools[B // 2, 3] += 0.01          # one arm with another hand: per-arm tools, the general variants
+    eng.set_tool(tools, per_arm=True)
+    assert eng.dh_pattern == 0
+    got = eng.step_host(w["q"], want=ALL)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=tools.astype(np.float32).astype(np.float64))
+    _check(got, ref, 1e-6, ALL)
+    eng.close()

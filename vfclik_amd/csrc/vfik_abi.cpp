@@ -652,6 +652,17 @@ int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm) {
         return upload_kconst(h);
     }
     const size_t B = h->B, Bp = h->Bpad;
+    {   // every arm with the same frame (a port-level caller forwards each arm's /tool bottle, and a fleet of one robot type carries one
+        // hand): that is the batch's shared tool, with the values as the per-arm image would hold them (rounded to the I/O type) -- the
+        // launch stays on the PLAIN kernels (vfik_kernel.hip, TOOLC) instead of the general variants, 6.9 against 10.6 us for C3N
+        bool same = true;
+        for (size_t b = 1; b < B && same; ++b) same = std::memcmp(tool16 + b * 16, tool16, 12 * sizeof(double)) == 0;
+        if (same) {
+            for (int k = 0; k < 12; ++k) h->tool_shared[k] = h->io_dtype == 32 ? (double)(float)tool16[k] : tool16[k];
+            h->tool_per_arm = 0;
+            return upload_kconst(h);
+        }
+    }
     std::vector<char> buf(3 * Bp * 4 * h->esz, 0);
     for (size_t b = 0; b < B; ++b)
         for (int k = 0; k < 12; ++k) {  // rows 0..2 of the 4x4 -> 3 quad planes
