@@ -2662,6 +2662,9 @@ __global__ void __launch_bounds__(256) probe_kernel(const T* pose, const T* goal
 #define VFIK_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // one wave per block: in-order LDS queue, no s_barrier needed
 template <typename T, int NJ, bool NS, int DHP>
 __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
+    // DHP: bit 0 the chain's DH pattern, bit 1 (TOOLC) ONE tool for the batch -- as in cycle_body (what vfclik itself runs is one or two arms with a hand)
+    constexpr int DHPAT = DHP & 1;
+    constexpr bool TOOLC = (DHP & 2) != 0;
     static_assert(NJ <= 8 && (!NS || NJ <= 7), "one lane per joint; the sign memory is for chains of up to 7 joints");
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, j = lane & 7;
@@ -2754,7 +2757,7 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
         Jm[i][0] = p[0]; Jm[i][1] = p[1]; Jm[i][2] = p[2];
         const double ci = cs[i], si = sn[i];
         // (the chain's DH pattern, as in cycle_body: links that are a renaming, links that keep their frame, links without offset)
-        const bool J_SWAP = (DhPattern<NJ, DHP>::SWAP >> i) & 1u, J_NONE = (DhPattern<NJ, DHP>::NONE >> i) & 1u, J_D0 = (DhPattern<NJ, DHP>::D0 >> i) & 1u;
+        const bool J_SWAP = (DhPattern<NJ, DHPAT>::SWAP >> i) & 1u, J_NONE = (DhPattern<NJ, DHPAT>::NONE >> i) & 1u, J_D0 = (DhPattern<NJ, DHPAT>::D0 >> i) & 1u;
         double xn[3], ym[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { xn[r] = si * R[3 * r + 1]; ym[r] = si * R[3 * r]; }
@@ -2787,6 +2790,15 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
         const double dx = p[0] - Jm[i][0], dy = p[1] - Jm[i][1], dz = p[2] - Jm[i][2];
         const double cx = Jm[i][4] * dz - Jm[i][5] * dy, cy = Jm[i][5] * dx - Jm[i][3] * dz, cz = Jm[i][3] * dy - Jm[i][4] * dx;
         Jm[i][0] = cx; Jm[i][1] = cy; Jm[i][2] = cz;
+    }
+    if constexpr (TOOLC) {   // A4 (vf:321-332): the field is evaluated at the tool pose; the flange frame is recomposed where /pose_no_tool asks for it
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double x = R[3 * r], y = R[3 * r + 1], z = R[3 * r + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = x * kc->tool[c] + y * kc->tool[4 + c] + z * kc->tool[8 + c];
+            p[r] += x * kc->tool[3] + y * kc->tool[7] + z * kc->tool[11];
+        }
     }
 
     // ---- A5: the repellers, one per lane and round; the group's sum through LDS in a fixed order
@@ -2825,6 +2837,16 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
         const double kr = nr > EPS_LEN ? speed * sc[1] * nri : 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { tw[k] = tot[k] * kt; tw[3 + k] = tot[3 + k] * kr; }
+    }
+    if constexpr (TOOLC) {  // A6 (vf:456-459): the twist at the flange, shifted by p_ee - p_tip = -Rt (Rtool^T t)
+        double c3[3], r3[3];
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx) c3[jx] = kc->tool[jx] * kc->tool[3] + kc->tool[4 + jx] * kc->tool[7] + kc->tool[8 + jx] * kc->tool[11];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) r3[r] = -(R[3 * r] * c3[0] + R[3 * r + 1] * c3[1] + R[3 * r + 2] * c3[2]);
+        tw[0] += tw[4] * r3[2] - tw[5] * r3[1];
+        tw[1] += tw[5] * r3[0] - tw[3] * r3[2];
+        tw[2] += tw[3] * r3[1] - tw[4] * r3[0];
     }
 
     // ---- A7: damped least squares (replicated)
@@ -2950,7 +2972,7 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) o[i] = (T)qn[i];
         }
-        if (a.pose || a.pose_nt) {  // identity tool: one frame
+        if (a.pose || a.pose_nt) {  // without a tool: one frame
             T fr[16];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -2965,6 +2987,21 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
                 for (int i = 0; i < 16; ++i) o[i] = fr[i];
             }
             if (a.pose_nt) {
+                if constexpr (TOOLC) {   // the flange frame: R = Rt Rtool^T, p = pt - R t
+                    double Rf[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            Rf[3 * r + c] = R[3 * r] * kc->tool[4 * c] + R[3 * r + 1] * kc->tool[4 * c + 1] + R[3 * r + 2] * kc->tool[4 * c + 2];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) fr[4 * r + c] = (T)Rf[3 * r + c];
+                        fr[4 * r + 3] = (T)(p[r] - (Rf[3 * r] * kc->tool[3] + Rf[3 * r + 1] * kc->tool[7] + Rf[3 * r + 2] * kc->tool[11]));
+                    }
+                }
                 T* o = static_cast<T*>(a.pose_nt) + (long)arm * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[i] = fr[i];
@@ -3108,6 +3145,58 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                !a.qdot_vf && !a.qdot_null && !a.pose && !a.pose_nt && !a.v6 && !a.qdist && !a.goal_dist && !a.active && !a.q_lo &&
                !a.q_ref_out;
     lean = lean_any && fastf;
+    // In-kernel rollouts (ROLL) exist for PLAIN chains of up to 7 joints; with a tool, IK weights or prismatic joints the loop-carried
+    // state no longer fits the registers (12-268 B of scratch per lane until round 3) and the rollout is stepped by the host side
+    // (vfik_abi.cpp, launch_cycles), as for the long chains.
+    if constexpr (NJ <= VFIK_ROLL_MAX_NJ && PL) {
+        if (a.n_cycles > 0) {
+            if (lean) {
+                launch_full<T, NJ, NS, PL, true, true, 1, -1, false, false, false, false, DHP>(a, grid, blk, lds_lean, stream);
+                return;
+            }
+            if (fastf) launch_full<T, NJ, NS, PL, true, true, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
+            else launch_full<T, NJ, NS, PL, true, false, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
+            return;
+        }
+    }
+    if constexpr (PL && NJ <= (NS ? 7 : 8)) {
+        // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
+        // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
+        const bool served = fastf && !fun && !mixo && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
+                            !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
+                            (NS || (a.flags == 0 && !a.null_control));
+        // Adopted where the same-box A/B wins (profiles/r03_latency_small_*.txt, 1 ... 4 096 arms): launches that publish the
+        // per-cycle rows (pose, pose_no_tool, qdotOut, qdotout, qdist) -18 ... -22 % at every size; qdot_out alone without the
+        // nullspace module -4 ... -20 %; qdot_out alone WITH it -7 ... -11 % for a handful of arms, +-3 % from 64 arms on.
+        const bool rows = a.qdot_vf || a.qdot_null || a.pose || a.pose_nt || a.qdist;
+        const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
+        // (with the batch's shared tool: the TOOLC variants, built for the chain's DH pattern where the joint count has one)
+        constexpr bool CAP8 = DHP == (DhPattern<NJ, 1>::SWAP != 0 ? 1 : 0);
+        if (served && a.B <= cap && a.plain == 2 && CAP8) {
+            if constexpr (CAP8) {
+                const dim3 g8((a.B + 7) / 8), b8(64);
+                if constexpr (VFIK_SCALAR_KERNARG && !NS)
+                    hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DHP | 2>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
+                                       a.slots_used, a.flags, a);
+                else
+                    hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DHP | 2>), g8, b8, 8 * 1024, stream, a);
+                if (sub8) *sub8 = 1;
+                return;
+            }
+        }
+        if (served && a.B <= cap && a.plain == 1) {
+            const dim3 g8((a.B + 7) / 8), b8(64);
+            // (with the nullspace module the scalar entry measures 1-2 % SLOWER -- one arm 5.83 against 5.73 us, C2F 7.17 against 7.07 --
+            // with or without a batch fetch of the block's other members: that variant keeps the block entry)
+            if constexpr (VFIK_SCALAR_KERNARG && !NS)
+                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
+                                   a.slots_used, a.flags, a);
+            else
+                hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, a);
+            if (sub8) *sub8 = 1;
+            return;
+        }
+    }
     if constexpr (PL) {
         if (a.plain == 2) {
             // ONE tool for the batch (`set tool`, old/README.old:84): the lean and the publishing-lean single-cycle float32 launches on
@@ -3152,44 +3241,6 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                 }
             }
             launch_v<T, NJ, NS, false, 0>(a_in, grid, blk, lds, stream, sub8);
-            return;
-        }
-    }
-    // In-kernel rollouts (ROLL) exist for PLAIN chains of up to 7 joints; with a tool, IK weights or prismatic joints the loop-carried
-    // state no longer fits the registers (12-268 B of scratch per lane until round 3) and the rollout is stepped by the host side
-    // (vfik_abi.cpp, launch_cycles), as for the long chains.
-    if constexpr (NJ <= VFIK_ROLL_MAX_NJ && PL) {
-        if (a.n_cycles > 0) {
-            if (lean) {
-                launch_full<T, NJ, NS, PL, true, true, 1, -1, false, false, false, false, DHP>(a, grid, blk, lds_lean, stream);
-                return;
-            }
-            if (fastf) launch_full<T, NJ, NS, PL, true, true, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
-            else launch_full<T, NJ, NS, PL, true, false, 0, -1, false, false, false, false, DHP>(a, grid, blk, lds, stream);
-            return;
-        }
-    }
-    if constexpr (PL && NJ <= (NS ? 7 : 8)) {
-        // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
-        // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
-        const bool served = fastf && !fun && !mixo && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded && !a.active && !a.q_lo &&
-                            !a.q_ref_out && !a.v6 && !a.goal_dist && !a.q_out && a.n_cycles == 0 && a.qdot_out &&
-                            (NS || (a.flags == 0 && !a.null_control));
-        // Adopted where the same-box A/B wins (profiles/r03_latency_small_*.txt, 1 ... 4 096 arms): launches that publish the
-        // per-cycle rows (pose, pose_no_tool, qdotOut, qdotout, qdist) -18 ... -22 % at every size; qdot_out alone without the
-        // nullspace module -4 ... -20 %; qdot_out alone WITH it -7 ... -11 % for a handful of arms, +-3 % from 64 arms on.
-        const bool rows = a.qdot_vf || a.qdot_null || a.pose || a.pose_nt || a.qdist;
-        const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
-        if (served && a.B <= cap) {
-            const dim3 g8((a.B + 7) / 8), b8(64);
-            // (with the nullspace module the scalar entry measures 1-2 % SLOWER -- one arm 5.83 against 5.73 us, C2F 7.17 against 7.07 --
-            // with or without a batch fetch of the block's other members: that variant keeps the block entry)
-            if constexpr (VFIK_SCALAR_KERNARG && !NS)
-                hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
-                                   a.slots_used, a.flags, a);
-            else
-                hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DHP>), g8, b8, 8 * 1024, stream, a);
-            if (sub8) *sub8 = 1;
             return;
         }
     }
