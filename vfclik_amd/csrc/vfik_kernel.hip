@@ -864,7 +864,9 @@ template <typename T, int NJ> struct ArenaLayout {
 template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES, bool UNI, bool MIXO, int DHP>
 __device__ __forceinline__ void
 cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, KLean, KArgs>::type& a_in) {
-    static_assert(DHP == 0 || (PLAIN && FASTF && !ROLL && !PERS && (LEAN == 1 || LEAN == 3) && sizeof(T) == 4), "DHP: the lean single-cycle straight-line float variants");
+    static_assert(DHP == 0 || (PLAIN && FASTF && (!ROLL || LEAN == 1) && !PERS && LEAN != 0 && sizeof(T) == 4), "DHP: the lean straight-line float variants (single cycle, a stepped rollout's cycle, and the lean rollout)");
+    static_assert(!(DHP & 2) || LEAN != 2, "TOOLC: not in a stepped rollout's cycle");
+    static_assert(!(DHP & 2) || !ROLL, "TOOLC: single-cycle variants only (a rollout with a tool is stepped)");
     // DHP bit 0: the chain's DH pattern (DhPattern<NJ, 1>); bit 1 (TOOLC): ONE tool for the whole batch, applied by the PLAIN kernel --
     // vfclik's normal state is an arm with a hand on it (`set tool`, old/README.old:84; vf:321-332), and until round 4 any tool sent the
     // launch to the general variants: C3 4.5 -> 8.0 us, C3N 6.6 -> 10.6 (profiles/r04_tool_cost.txt).  A compile-time property like the
@@ -3065,10 +3067,10 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
 // Launch of a KLean variant (lean, single cycle, straight-line field path): scalar kernel arguments, or the argument block.
 // UNI variants read the uniform repeller image, which sits a.uni_planes quad planes behind the compact one: the offset rides in the
 // upper bits of fast_order (KLean's fourteen dwords are all taken).
-// The DH pattern a variant is built with: the requested one for the lean / publishing-lean single-cycle straight-line float variants
+// The DH pattern a variant is built with: the requested one for the lean / publishing-lean single-cycle straight-line float variants and the lean rollout
 // (not the persistent one), none for every other variant -- so that asking for a pattern never multiplies the kernels of the rest.
 template <typename T, bool PL, bool ROLL, bool FASTF, int LEAN, bool PERS>
-constexpr int dhp_of(int dhp) { return (sizeof(T) == 4 && PL && !ROLL && FASTF && (LEAN == 1 || LEAN == 3) && !PERS) ? dhp : 0; }
+constexpr int dhp_of(int dhp) { return (sizeof(T) == 4 && PL && FASTF && (ROLL ? LEAN == 1 : LEAN != 0) && !PERS) ? dhp : 0; }
 
 template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false, int DHP = 0>
 void launch_lean(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
