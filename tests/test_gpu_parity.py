@@ -373,6 +373,42 @@ def test_every_row_published_at_lane_per_arm_batch_sizes(env, robot, dt, tol, wi
     assert np.abs(got["pose"][:, 15] - 1.0).max() == 0.0 and np.abs(got["pose_nt"][:, 12:15]).max() == 0.0
 
 
+@pytest.mark.parametrize("robot,dt,tol,B", [("lwr_dual14", np.float64, TOL64, 4096 + 70), ("lwr_dual14", np.float32, TOL32, 300),
+                                            ("lwr", np.float64, TOL64, 4096 + 70)])
+def test_per_arm_tools_and_mixer_weights_use_the_tail_of_the_lds_region(env, robot, dt, tol, B):
+    """Per-arm tools and per-arm mixer weights are the last rows of a wave's LDS region; launches whose full region does not fit a CU four
+    times (float64 I/O, 14 joints: 44 KB) go as one wave per block and ask for those rows only when the options are set (launch_t).
+    Both options set, then cleared again on the same handle; the straight-line and the general field path.  vf:321-332, command_mixer.py:48-53."""
+    chain = getattr(env.robots, robot)()
+    rng = np.random.default_rng(23)
+    f = env.abi
+    mw = [0.8, 0.5, 0.0, 0.0, 0.0, 0.0]
+    params = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER | f.F_JOINT_LIMIT_TASK, mix_w=mw)
+    tools = np.tile(np.eye(4), (B, 1, 1))
+    tools[:, :3, 3] = rng.uniform(-0.2, 0.2, (B, 3))
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    tools[:, :3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    tools = tools.reshape(B, 16).astype(dt).astype(np.float64)
+    for general in (False, True):
+        w = env.synth.make_workload(chain, B, 6, seed=24, io_dtype=dt)
+        if general:
+            w["fields"]["p"][B // 3, 2, 5] = 2.5   # a fractional decay order: the whole batch on the general path
+        eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=8, params=params)
+        eng.set_fields(w["fields"], w["nfields"])
+        assert eng.field_path == (0 if general else 1)
+        eng.set_tool(tools, per_arm=True)
+        eng.set_mixer_weights(np.tile(mw, (B, 1)))
+        got = eng.step_host(w["q"], want=ALL)
+        ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=tools)
+        _compare(got, ref, tol, ALL)
+        eng.set_mixer_weights(None)
+        eng.set_tool(np.eye(4).reshape(16))
+        got = eng.step_host(w["q"], want=ALL)
+        ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"])
+        _compare(got, ref, tol, ALL)
+        eng.close()
+
+
 @pytest.mark.parametrize("robot,dt,tol", [("lwr", np.float64, 1e-9), ("lwr", np.float32, 2e-5), ("lwr_dual14", np.float64, 1e-9)])
 def test_ik_weights_of_each_arm(env, robot, dt, tol):
     """Every arm's vf process keeps its own 't' / 'j' weights (vf:164-179,295-309): three groups of arms with
