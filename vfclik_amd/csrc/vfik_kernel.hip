@@ -3370,7 +3370,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
 #endif
 }
 
-template <typename T, int NJ>
+template <typename T, int NJ, bool NS>   // NS: the launch's flags carry VFIK_F_NULLSPACE (decided by the caller: one object per (n, T, NS))
 hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     KArgs a = a0;
     // (VFIK_BLOCK is a tuning knob: a block's waves must fit the CU's 160 KB of LDS with their regions)
@@ -3388,29 +3388,26 @@ hipError_t launch_t(const KArgs& a0, int block, hipStream_t stream, int* sub8) {
     }
     a.block = block;
     const dim3 grid((a.B + block - 1) / block), blk(block);
-    const bool ns = a.flags & VFIK_F_NULLSPACE;
     if (a.n_cycles > 0 && (a.plain != 1 || NJ > VFIK_ROLL_MAX_NJ)) return hipErrorInvalidValue;   // (stepped by the caller: launch_cycles; a tool too -- the rollout variants have no register to spare for it)
     if (a.plain) {
         if constexpr (DhPattern<NJ, 1>::SWAP != 0) {   // (float64 I/O: only the eight-lanes kernel has pattern variants, dhp_of)
             if (a.dhp == 1) {   // the chain matches the DH pattern built for this joint count (vfik_abi.cpp: upload_kconst)
-                if (ns) launch_v<T, NJ, true, true, 1>(a, grid, blk, lds, stream, sub8);
-                else launch_v<T, NJ, false, true, 1>(a, grid, blk, lds, stream, sub8);
+                launch_v<T, NJ, NS, true, 1>(a, grid, blk, lds, stream, sub8);
                 return hipGetLastError();
             }
         }
-        if (ns) launch_v<T, NJ, true, true>(a, grid, blk, lds, stream, sub8);
-        else launch_v<T, NJ, false, true>(a, grid, blk, lds, stream, sub8);
+        launch_v<T, NJ, NS, true>(a, grid, blk, lds, stream, sub8);
     } else {
-        if (ns) launch_v<T, NJ, true, false>(a, grid, blk, lds, stream, sub8);
-        else launch_v<T, NJ, false, false>(a, grid, blk, lds, stream, sub8);
+        launch_v<T, NJ, NS, false>(a, grid, blk, lds, stream, sub8);
     }
     return hipGetLastError();
 }
 
 }  // namespace
 
-// The library is built from this one source compiled several times (csrc/Makefile): once per joint
-// count with -DVFIK_ONLY_NJ=<n> (the kernels of that n, in parallel make jobs) and once with
+// The library is built from this one source compiled several times (csrc/Makefile): per joint count, I/O type and with / without the
+// nullspace module with -DVFIK_ONLY_NJ=<n> -DVFIK_ONLY_T=<32|64> -DVFIK_ONLY_NS=<0|1> (the kernels of that combination, in parallel make
+// jobs: sixteen objects of 20-70 kernels each instead of four of 85-160), once per long chain with -DVFIK_HEAVY_PART, and once with
 // -DVFIK_DISPATCH (launch dispatch, mixer kernel, host-side constant preparation).
 #ifdef VFIK_ONLY_NJ
 #ifdef VFIK_HEAVY_PART
@@ -3431,14 +3428,24 @@ void VFIK_CAT(launch_heavy_nj, VFIK_ONLY_NJ)(int io_dtype, bool ns, bool plain, 
 #undef VFIK_HEAVY
 }
 #else
-hipError_t VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ)(int io_dtype, const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
-    return io_dtype == 32 ? launch_t<float, VFIK_ONLY_NJ>(kargs, block, stream, sub8) : launch_t<double, VFIK_ONLY_NJ>(kargs, block, stream, sub8);
+#if VFIK_ONLY_T == 32
+typedef float VfikOnlyT;
+#else
+typedef double VfikOnlyT;
+#endif
+#define VFIK_PART_NAME VFIK_CAT(VFIK_CAT(VFIK_CAT(VFIK_CAT(VFIK_CAT(launch_cycle_nj, VFIK_ONLY_NJ), _t), VFIK_ONLY_T), _ns), VFIK_ONLY_NS)
+hipError_t VFIK_PART_NAME(const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
+    return launch_t<VfikOnlyT, VFIK_ONLY_NJ, VFIK_ONLY_NS != 0>(kargs, block, stream, sub8);
 }
 #endif
 }  // namespace vfik
 #else  // VFIK_DISPATCH
 
-#define X(n) hipError_t launch_cycle_nj##n(int io_dtype, const KArgs& kargs, int block, hipStream_t stream, int* sub8);
+#define X(n)                                                                                                      \
+    hipError_t launch_cycle_nj##n##_t32_ns0(const KArgs& kargs, int block, hipStream_t stream, int* sub8);       \
+    hipError_t launch_cycle_nj##n##_t32_ns1(const KArgs& kargs, int block, hipStream_t stream, int* sub8);       \
+    hipError_t launch_cycle_nj##n##_t64_ns0(const KArgs& kargs, int block, hipStream_t stream, int* sub8);       \
+    hipError_t launch_cycle_nj##n##_t64_ns1(const KArgs& kargs, int block, hipStream_t stream, int* sub8);
 VFIK_NJ_LIST
 #undef X
 
@@ -3610,8 +3617,12 @@ uint32_t supported_joints_mask() {
 }
 
 hipError_t launch_cycle(int io_dtype, int nj, const KArgs& kargs, int block, hipStream_t stream, int* sub8) {
+    const bool ns = kargs.flags & VFIK_F_NULLSPACE;
     switch (nj) {
-#define X(n) case n: return launch_cycle_nj##n(io_dtype, kargs, block, stream, sub8);
+#define X(n)                                                                                                                        \
+    case n:                                                                                                                         \
+        return io_dtype == 32 ? (ns ? launch_cycle_nj##n##_t32_ns1(kargs, block, stream, sub8) : launch_cycle_nj##n##_t32_ns0(kargs, block, stream, sub8))  \
+                              : (ns ? launch_cycle_nj##n##_t64_ns1(kargs, block, stream, sub8) : launch_cycle_nj##n##_t64_ns0(kargs, block, stream, sub8));
         VFIK_NJ_LIST
 #undef X
         default: return hipErrorInvalidValue;
