@@ -79,7 +79,7 @@ int vfik_set_params(vfik_handle* h, const vfik_params* p);
 int vfik_set_speed_scale(vfik_handle* h, int first_arm, int n_arms, const double* values);
 
 /* /tool (vf:321-326): 16 doubles row-major, shared by the batch (per_arm = 0) or tool16[B][16].  ONE tool for the batch keeps the
- * launches of an all-revolute chain with unit IK weights on the kernels built for such chains (the lean and publishing-lean float32-I/O
+ * launches of an all-revolute chain on the kernels built for such chains (the lean and publishing-lean float32-I/O
  * variants apply it themselves); per-arm tools take the general variants.  A per-arm array whose rows are all equal IS a
  * shared tool and is stored as one (with the values rounded to the I/O type, as the per-arm image would hold them). */
 int vfik_set_tool(vfik_handle* h, const double* tool16, int per_arm);
@@ -302,7 +302,7 @@ long vfik_launch_epoch(vfik_handle* h);
 /* ABI 5, introspection.  1 when the chain set by vfik_set_chain matches a Denavit-Hartenberg pattern the lean float32-I/O kernels (and
  * the eight-lanes-per-arm kernel of small batches, either I/O type) are built for -- for 7 joints the KUKA LWR 4+ (vfclik's default robot, scripts/vfclik:42): a = 0 on every link, alpha = +-pi/2 on six,
  * d = 0 on three; for 14 joints two of them in series; for 6 joints the arm of vfclik_amd/robots.py -- and launches may take the
- * variants in which those links cost no arithmetic (all-revolute chain, unit IK weights, no tool or ONE tool for the batch); 0 otherwise: every
+ * variants in which those links cost no arithmetic (all-revolute chain; no tool or ONE tool for the batch; IK weights shared by the batch); 0 otherwise: every
  * chain runs, the general DH form is the fallback.  VFIK_DH_PATTERN=0 in the environment switches the specialisation off. */
 int vfik_dh_pattern(vfik_handle* h);
 size_t vfik_device_bytes(vfik_handle* h);

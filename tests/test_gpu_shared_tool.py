@@ -157,3 +157,73 @@ def test_equal_per_arm_tools_are_the_shared_tool(env):
     ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=tools.astype(np.float32).astype(np.float64))
     _check(got, ref, 1e-6, ALL)
     eng.close()
+
+
+@pytest.mark.parametrize("robot,B,nobs,dt,tol,flags,want,with_tool", [
+    ("lwr", 65536, 8, np.float32, 1e-6, 5, ("qdot_out", "status"), False),
+    ("lwr", 65536, 8, np.float32, 1e-6, 0, ("qdot_out", "status"), True),
+    ("lwr", 8192 + 37, 8, np.float32, 1e-6, 7, ALL, False),
+    ("lwr", 8192 + 37, 8, np.float32, 1e-6, 7, ALL, True),
+    ("lwr", 1, 4, np.float64, 1e-9, 5, ALL, False),
+    ("lwr", 2, 4, np.float64, 1e-9, 5, ALL, True),
+    ("lwr", 777, 8, np.float32, 1e-6, 5, ("qdot_out", "pose", "pose_nt", "qdist", "status"), True),
+    ("lwr", 5000, 4, np.float64, 1e-9, 5, ALL, False),            # float64 beyond the eight-lanes sizes: the general variants
+    ("powercube6", 5000, 6, np.float32, 1e-6, 0, ALL, False),
+    ("powercube6", 300, 6, np.float64, 1e-9, 0, ALL, True),
+    ("lwr_dual14", 4096 + 64 + 3, 16, np.float32, 1e-6, 7, ALL, False),   # 14 joints: weights take the general variants
+])
+def test_shared_ik_weights_on_the_plain_variants(env, robot, B, nobs, dt, tol, flags, want, with_tool):
+    """IK weights other than one for the whole batch (/weight, vf:295-309: 't' and 'j' weights; handlers.set_wik_*) on the kernels built
+    for plain chains (WTSC), alone and together with the shared tool; then back to unit weights on the same handle."""
+    chain = getattr(env.robots, robot)()
+    n = chain.n
+    rng = np.random.default_rng(57)
+    w = env.synth.make_workload(chain, B, nobs, seed=55, io_dtype=dt)
+    wy = [1.0, 1.0, 1.0, 0.3, 0.3, 0.1]
+    wq = list(rng.uniform(0.2, 1.0, n)) + [1.0] * (16 - n)
+    params = env.abi.default_params(flags=flags, wy=wy, wq=wq)
+    tool = _tool() if with_tool else None
+    eng = env.engine.Engine(chain, B, io_dtype=dt, max_slots=max(8, nobs), params=params)
+    eng.set_fields(w["fields"], w["nfields"])
+    if with_tool:
+        eng.set_tool(tool)
+    assert eng.field_path == 1 and eng.dh_pattern == 1
+    got = eng.step_host(w["q"], want=want)
+    ref = env.oc.cycle_batch(chain, params, w["q"], w["fields"], w["nfields"], tool=tool)
+    _check(got, ref, tol, want)
+    plain = env.abi.default_params(flags=flags)
+    ref1 = env.oc.cycle_batch(chain, plain, w["q"], w["fields"], w["nfields"], tool=tool)
+    assert np.abs(ref["qdot_out"] - ref1["qdot_out"]).max() > 1e-3    # (the weights really act)
+    eng.set_params(wy=[1.0] * 6, wq=[1.0] * 16)
+    got = eng.step_host(w["q"], want=want)
+    _check(got, ref1, tol, want)
+    eng.close()
+
+
+def test_shared_weights_with_the_aux_block_and_differing_orders(env):
+    """The README scene with a tool AND joint weights: order planes, aux block, TOOLC and WTSC in one launch."""
+    chain = env.robots.lwr()
+    B = 4096 + 64 + 9
+    w = env.synth.make_workload(chain, B, 5, seed=58, io_dtype=np.float32, max_fields=8)
+    F = w["fields"]
+    F["id"][:, 6], F["type"][:, 6], F["force"][:, 6] = 2, 5, 30.0
+    F["p"][:, 6, 0:3] = F["p"][:, 0, [3, 7, 11]]
+    F["p"][:, 6, 3:6] = F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 6, 6:10] = [0.15, 10.0, 0.15, 2.0]
+    F["id"][:, 7], F["type"][:, 7], F["force"][:, 7] = 3, 2, -10.0
+    F["p"][:, 7, 0:3] = F["p"][:, 0, [3, 7, 11]] - 0.05 * F["p"][:, 0, [2, 6, 10]]
+    F["p"][:, 7, 3:6] = [0.05, 0.001, 5.0]
+    F["p"][:, 1:6, 5] = 20.0
+    F["p"][:, 1:6, 3] = 0.05
+    w["nfields"][:] = 8
+    params = env.abi.default_params(flags=5, wq=[1, 0.5, 1, 0.7, 1, 0.4, 1] + [1.0] * 9)
+    tool = _tool(rot=False)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=10, params=params)
+    eng.set_fields(F, w["nfields"])
+    eng.set_tool(tool)
+    assert eng.field_path == 2 and eng.mixed_orders == 1
+    for want in (("qdot_out", "status"), ALL):
+        got = eng.step_host(w["q"], want=want)
+        ref = env.oc.cycle_batch(chain, params, w["q"], F, w["nfields"], tool=tool)
+        _check(got, ref, 1e-6, want)
+    eng.close()

@@ -23,3 +23,4 @@ run("C3 (no module), tool 0 0 0.2", 0, True)
 run("C3N (nullspace+mixer), no tool", 5, False)
 run("C3N, tool 0 0 0.2", 5, True)
 run("C3N, joint weights", 5, False, wq=[0.5]*7 + [1.0]*9)
+run("C3N, joint weights and tool", 5, True, wq=[0.5]*7 + [1.0]*9)

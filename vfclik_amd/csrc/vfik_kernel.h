@@ -66,16 +66,16 @@ struct KConst {
     // shared tool frame (rows 0..2 of the 4x4; per-arm tools are a device array).  In the rows every wave copies to LDS: with the inputs
     // cold a scalar load from the tail of the block is an HBM round trip of its own (measured on a flag there: C3 +7 %, profiles/r04_ab_tool.txt)
     double tool[12];
+    double wy[6];    // the batch's IK weights (/weight, vf:295-309), in the copied rows for the same reason
+    double wq[NJ];
     double q_lo[NJ];
     double q_hi[NJ];
     double q_mid[NJ];     // (lo + hi) / 2
     double inv_half[NJ];  // 2 / (hi - lo)
     double jl_k[NJ];      // jl_gain / half^2
-    double wq[NJ];
-    double wy[6];
     unsigned prismatic_mask;
     unsigned pad0;
-    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4 + 10 + VFIK_MIX_CHANNELS + 12) * 8;  // through tool: the block every wave copies to LDS
+    static constexpr int KIN_BYTES = (12 + 10 * NJ + 4 + 10 + VFIK_MIX_CHANNELS + 12 + 6 + NJ) * 8;  // through wq: the block every wave copies to LDS
     static constexpr int KIN_ROWS = (KIN_BYTES + 1023) / 1024;  // 1-KiB LDS rows / requests
 };
 // The device image of the constants is KConst<NJ> padded to a multiple of 1 KiB, then the 1-KiB sin / cos table
@@ -85,7 +85,8 @@ struct KConst {
 #define VFIK_KCONST_REP_SAFE_OFF(nj) ((12 + 10 * (nj) + 3) * 8)
 static_assert(offsetof(KConst<7>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(7) && offsetof(KConst<14>, rep_safe) == VFIK_KCONST_REP_SAFE_OFF(14), "KConst::rep_safe");
 static_assert(offsetof(KConst<7>, dh) + offsetof(KConst<7>::DH, pad) == VFIK_KCONST_REP_FORCE_OFF, "KConst::dh[0].pad");
-static_assert(offsetof(KConst<7>, tool) + 96 == KConst<7>::KIN_BYTES && offsetof(KConst<14>, tool) + 96 == KConst<14>::KIN_BYTES, "KConst::tool closes the LDS-copied block");
+static_assert(offsetof(KConst<7>, wq) + 7 * 8 == KConst<7>::KIN_BYTES && offsetof(KConst<14>, wq) + 14 * 8 == KConst<14>::KIN_BYTES, "KConst::wq closes the LDS-copied block");
+static_assert(KConst<7>::KIN_BYTES <= 1024 && KConst<6>::KIN_BYTES <= 1024 && KConst<10>::KIN_BYTES <= 2048 && KConst<14>::KIN_BYTES <= 2048, "the copied block keeps its row count");
 template <int NJ> struct KTab { static constexpr int OFFSET = ((int)sizeof(KConst<NJ>) + 1023) / 1024 * 1024; };
 
 // DH patterns the lean kernels are built for (cycle_body, DHP): per joint count, bit i of

@@ -673,7 +673,7 @@ template <typename T> struct Stage {
     __host__ __device__ static constexpr int q16(int nj) { return qbytes(nj) / 16; }
     __host__ __device__ static constexpr int qrem(int nj) { return qbytes(nj) % 16; }
     __host__ __device__ static constexpr int qregion(int nj) { return q16(nj) * 1024 + qrem(nj) * 64; }
-    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4 + 10 + VFIK_MIX_CHANNELS + 12) * 8 + 1023) / 1024; }  // = KConst<nj>::KIN_ROWS
+    __host__ __device__ static constexpr int kin_rows(int nj) { return ((12 + 10 * nj + 4 + 10 + VFIK_MIX_CHANNELS + 12 + 6 + nj) * 8 + 1023) / 1024; }  // = KConst<nj>::KIN_ROWS
     __host__ __device__ static constexpr int kin_off(int nj) { return Q_OFF + qregion(nj); }
     __host__ __device__ static constexpr int tab_off(int nj) { return kin_off(nj) + kin_rows(nj) * 1024; }  // sin / cos table, 1 KiB
     __host__ __device__ static constexpr int lean_bytes(int nj) { return tab_off(nj) + 1024; }
@@ -874,6 +874,12 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     // straight-line code; profiles/r04_ab_tool.txt).
     constexpr int DHPAT = DHP & 1;
     constexpr bool TOOLC = (DHP & 2) != 0;
+    // DHP bit 2 (WTSC): the batch's IK weights (/weight, vf:295-309: Wy = diag of the 't' weights, Wq of the 'j' weights) other than one, on the
+    // PLAIN kernel of a chain of up to 7 joints -- the weighted normal matrix and the two scalings, ~80 instructions, instead of the general
+    // variants' run-time everything (C3N 6.7 -> 10.6 us).  WEIGHTED = what the general variants always do.
+    constexpr bool WTSC = (DHP & 4) != 0;
+    static_assert(!WTSC || (NJ <= 7 && !ROLL && LEAN != 2), "WTSC: single-cycle variants of chains of up to 7 joints");
+    constexpr bool WEIGHTED = !PLAIN || WTSC;
     static_assert(!MIXO || (FASTF && PLAIN && !ROLL && !PERS && !UNI && WAVES == 1 && (LEAN == 1 || LEAN == 3)), "MIXO: the lean single-cycle straight-line variants");
     static_assert(!PERS || (LEAN == 1 && FASTF && PLAIN && !ROLL && sizeof(T) == 4 && NJ <= 7 && !FUN), "PERS: lean straight-line float launches only");
     static_assert(!FUN || (FASTF && PLAIN && !ROLL && (LEAN == 1 || LEAN == 3)), "FUN: the lean single-cycle straight-line variants");
@@ -1499,15 +1505,15 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
     // Weighted form (vf:295-309: Wy = diag of the 't' weights, Wq of the 'j' weights), without a weighted copy of the
     // Jacobian: A = Wy (J Wq^2 J^T) Wy + lambda^2 I and qdot = Wq^2 J^T (Wy y).  (Until round 3 the general variants kept
     // Sw = Wy J Wq beside J: 12 n more registers, which the 10- and 14-joint kernels and the rollouts spilled to scratch.)
-    double wyv[PLAIN ? 1 : 6];
+    double wyv[WEIGHTED ? 6 : 1];
     auto wq2_of = [&](int i) {  // wq_i^2 of this arm
         const double wqi = wts ? wts[(long)(6 + i) * wpitch] : kc->wq[i];
         return wqi * wqi;
     };
     auto ik_factor = [&]() {
-        if constexpr (!PLAIN) {
+        if constexpr (WEIGHTED) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) wyv[PLAIN ? 0 : r] = wts ? wts[(long)r * wpitch] : kc->wy[r];
+            for (int r = 0; r < 6; ++r) wyv[WEIGHTED ? r : 0] = wts ? wts[(long)r * wpitch] : kc->wy[r];
         }
         constexpr bool GFROMA = FUSEP && PLAIN && !GLATE;  // unit weights: G is A before the damping is added
         if constexpr (ACCJ) {  // accumulated with the Jacobian columns above
@@ -1522,7 +1528,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && PLAIN) ? HOTK(lambda2) : 0.0;
+                for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !GFROMA && !WEIGHTED) ? HOTK(lambda2) : 0.0;
             if constexpr (FUSEP && !GLATE) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
@@ -1534,7 +1540,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {  // joint by joint: 21 independent accumulators per step
                 double t[6];
-                if constexpr (!PLAIN) {
+                if constexpr (WEIGHTED) {
                     const double w2 = wq2_of(i);
 #pragma unroll
                     for (int r = 0; r < 6; ++r) t[r] = w2 * Jm[i][r];
@@ -1544,7 +1550,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                     if (jzero(i, r)) continue;
 #pragma unroll
                     for (int c = 0; c <= r; ++c)
-                        if (!jzero(i, c)) A[r][c] = __builtin_fma(PLAIN ? Jm[i][r] : t[r], Jm[i][c], A[r][c]);
+                        if (!jzero(i, c)) A[r][c] = __builtin_fma(WEIGHTED ? t[r] : Jm[i][r], Jm[i][c], A[r][c]);
                     if constexpr (FUSEP && !GLATE) {
                         wn[r] = __builtin_fma(Jm[i][r], zp[i], wn[r]);
                         if constexpr (!PLAIN) {
@@ -1554,11 +1560,11 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                     }
                 }
             }
-            if constexpr (!PLAIN) {  // A <- Wy A Wy + lambda^2 I
+            if constexpr (WEIGHTED) {  // A <- Wy A Wy + lambda^2 I
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(wyv[PLAIN ? 0 : r] * wyv[PLAIN ? 0 : c], A[r][c], r == c ? HOTK(lambda2) : 0.0);
+                    for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(wyv[WEIGHTED ? r : 0] * wyv[WEIGHTED ? c : 0], A[r][c], r == c ? HOTK(lambda2) : 0.0);
             }
         }
         if constexpr (GFROMA) {
@@ -1990,7 +1996,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
         double y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double t = PLAIN ? tw[i] : wyv[PLAIN ? 0 : i] * tw[i];
+            double t = WEIGHTED ? wyv[WEIGHTED ? i : 0] * tw[i] : tw[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
             y[i] = t;
@@ -2068,9 +2074,9 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
 #pragma unroll
                 for (int k = i + 1; k < 6; ++k) wn[i] = __builtin_fma(-Gm[FUSEP ? k : 0][i], wn[k], wn[i]);
         }
-        if constexpr (!PLAIN) {  // qdot = Wq^2 J^T (Wy y)
+        if constexpr (WEIGHTED) {  // qdot = Wq^2 J^T (Wy y)
 #pragma unroll
-            for (int r = 0; r < 6; ++r) y[r] *= wyv[PLAIN ? 0 : r];
+            for (int r = 0; r < 6; ++r) y[r] *= wyv[WEIGHTED ? r : 0];
         }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
@@ -2085,7 +2091,7 @@ cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::v
                 qv[i] = __builtin_fma(Jm[i][r], y[r], qv[i]);
                 if constexpr (FUSEP) zp[i] = __builtin_fma(-Jm[i][r], wn[r], zp[i]);
             }
-        if (!PLAIN) {
+        if (WEIGHTED) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) qv[i] *= wq2_of(i);
         }
@@ -2667,6 +2673,7 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
     // DHP: bit 0 the chain's DH pattern, bit 1 (TOOLC) ONE tool for the batch -- as in cycle_body (what vfclik itself runs is one or two arms with a hand)
     constexpr int DHPAT = DHP & 1;
     constexpr bool TOOLC = (DHP & 2) != 0;
+    constexpr bool WTSC = (DHP & 4) != 0;    // bit 2: the batch's IK weights other than one (cycle_body, WTSC)
     static_assert(NJ <= 8 && (!NS || NJ <= 7), "one lane per joint; the sign memory is for chains of up to 7 joints");
     const int lane = threadIdx.x & 63;
     const int g = lane >> 3, j = lane & 7;
@@ -2856,13 +2863,26 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) A[r][c] = r == c ? kc->lambda2 : 0.0;
+        for (int c = 0; c <= r; ++c) A[r][c] = (r == c && !WTSC) ? kc->lambda2 : 0.0;
 #pragma unroll
-    for (int i = 0; i < NJ; ++i)
+    for (int i = 0; i < NJ; ++i) {
+        double t[6];
+        if constexpr (WTSC) {   // A = Wy (J Wq^2 J^T) Wy + lambda^2 I, qdot = Wq^2 J^T (Wy y): as cycle_body
+            const double w2 = kc->wq[i] * kc->wq[i];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[r] = w2 * Jm[i][r];
+        }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(Jm[i][r], Jm[i][c], A[r][c]);
+            for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(WTSC ? t[r] : Jm[i][r], Jm[i][c], A[r][c]);
+    }
+    if constexpr (WTSC) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) A[r][c] = __builtin_fma(kc->wy[r] * kc->wy[c], A[r][c], r == c ? kc->lambda2 : 0.0);
+    }
 #pragma unroll
     for (int jj = 0; jj < 6; ++jj) {
         double v[6];
@@ -2883,7 +2903,7 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        double t = tw[i];
+        double t = WTSC ? kc->wy[i] * tw[i] : tw[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) t -= A[i][k] * y[k];
         y[i] = t;
@@ -2897,12 +2917,17 @@ __device__ __forceinline__ void cycle_sub8_body(const KArgs& a) {
         for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k];
         y[i] = t;
     }
+    if constexpr (WTSC) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) y[r] *= kc->wy[r];
+    }
     double qv[NJ], qn[NJ], qo[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         qv[i] = Jm[i][0] * y[0];
 #pragma unroll
         for (int r = 1; r < 6; ++r) qv[i] = __builtin_fma(Jm[i][r], y[r], qv[i]);
+        if constexpr (WTSC) qv[i] *= kc->wq[i] * kc->wq[i];
         qn[i] = 0.0;
     }
 
@@ -3161,6 +3186,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             return;
         }
     }
+    bool small8 = false;   // a launch the eight-lanes kernel serves, at a size where it wins
     if constexpr (PL && NJ <= (NS ? 7 : 8)) {
         // small batches: eight lanes per arm (cycle_sub8_kernel) for the launches it serves -- the straight-line field path, no
         // per-arm option, the outputs the per-arm processes publish every cycle.  VFIK_SUB8_MAX_BATCH = 0 switches it off.
@@ -3172,20 +3198,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         // nullspace module -4 ... -20 %; qdot_out alone WITH it -7 ... -11 % for a handful of arms, +-3 % from 64 arms on.
         const bool rows = a.qdot_vf || a.qdot_null || a.pose || a.pose_nt || a.qdist;
         const int cap = rows ? a.sub8_max_batch_full : (NS ? a.sub8_max_batch_ns : a.sub8_max_batch);
-        // (with the batch's shared tool: the TOOLC variants, built for the chain's DH pattern where the joint count has one)
-        constexpr bool CAP8 = DHP == (DhPattern<NJ, 1>::SWAP != 0 ? 1 : 0);
-        if (served && a.B <= cap && a.plain == 2 && CAP8) {
-            if constexpr (CAP8) {
-                const dim3 g8((a.B + 7) / 8), b8(64);
-                if constexpr (VFIK_SCALAR_KERNARG && !NS)
-                    hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DHP | 2>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B, a.Bpad,
-                                       a.slots_used, a.flags, a);
-                else
-                    hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DHP | 2>), g8, b8, 8 * 1024, stream, a);
-                if (sub8) *sub8 = 1;
-                return;
-            }
-        }
+        small8 = served && a.B <= cap;   // (with a shared tool / shared IK weights: the option block below launches this kernel's variants)
         if (served && a.B <= cap && a.plain == 1) {
             const dim3 g8((a.B + 7) / 8), b8(64);
             // (with the nullspace module the scalar entry measures 1-2 % SLOWER -- one arm 5.83 against 5.73 us, C2F 7.17 against 7.07 --
@@ -3200,19 +3213,35 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
         }
     }
     if constexpr (PL) {
-        if (a.plain == 2) {
-            // ONE tool for the batch (`set tool`, old/README.old:84): the lean and the publishing-lean single-cycle float32 launches on
-            // the straight-line path -- what the default process set asks of an array caller and of ControlCycleBatch -- have PLAIN
-            // variants that apply it (cycle_body, TOOLC = DHP bit 1; run-time flags; with the uniform image, the aux block, the order
-            // planes), for the chain's DH pattern where one is built for the joint count.  Every other launch with a tool (float64 I/O,
-            // a rollout, per-arm options, the general field path, a chain off its pattern) takes the general variants, as until round 4.
-            constexpr bool CAP = sizeof(T) == 4 && DHP == (DhPattern<NJ, 1>::SWAP != 0 ? 1 : 0);
-            if constexpr (CAP) {
-                constexpr int DT = DHP | 2;
-                const bool lean1 = lean && !a.q_out && a.n_cycles == 0;
-                const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
-                                   !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
-                if (lean1 || lean3) {
+        if (a.plain >= 2) {
+            // The batch's shared options on the kernels built for plain chains: ONE tool for the batch (`set tool`, old/README.old:84;
+            // a.plain - 1 bit 0) and / or IK weights other than one (/weight, vf:295-309; bit 1).  The lean and the publishing-lean
+            // single-cycle float32 launches on the straight-line path -- what the default process set asks of an array caller and of
+            // ControlCycleBatch -- and the eight-lanes kernel (both I/O types) have variants that apply them (cycle_body / cycle_sub8_body:
+            // TOOLC = DHP bit 1, WTSC = DHP bit 2, the latter for chains of up to 7 joints; run-time flags; with the uniform image, the aux
+            // block, the order planes), for the chain's DH pattern where one is built for the joint count.  Every other launch of such a
+            // handle (float64 I/O beyond the eight-lanes sizes, a rollout, per-arm options, the general field path, a chain off its
+            // pattern) takes the general variants, as until round 4.
+            constexpr bool PAT = DHP == (DhPattern<NJ, 1>::SWAP != 0 ? 1 : 0);
+            auto launch_opt = [&](auto dt) -> bool {
+                constexpr int DT = decltype(dt)::value;
+                if constexpr (PL && NJ <= (NS ? 7 : 8)) {
+                    if (small8) {
+                        const dim3 g8((a.B + 7) / 8), b8(64);
+                        if constexpr (VFIK_SCALAR_KERNARG && !NS)
+                            hipLaunchKernelGGL((cycle_sub8_kernel_x<T, NJ, NS, DT>), g8, b8, 8 * 1024, stream, (const void*)a.arena, a.q, a.qdot_out, a.null_control, a.slots, a.B,
+                                               a.Bpad, a.slots_used, a.flags, a);
+                        else
+                            hipLaunchKernelGGL((cycle_sub8_kernel<T, NJ, NS, DT>), g8, b8, 8 * 1024, stream, a);
+                        if (sub8) *sub8 = 1;
+                        return true;
+                    }
+                }
+                if constexpr (sizeof(T) == 4) {
+                    const bool lean1 = lean && !a.q_out && a.n_cycles == 0;
+                    const bool lean3 = fastf && (NS || a.flags == 0) && !a.tool_stride && !a.mixw && !a.wts && !a.ext && !a.q_ref && !a.q_cmded &&
+                                       !a.q_lo && !a.q_ref_out && !a.q_out && a.n_cycles == 0;
+                    if (!(lean1 || lean3)) return false;
                     if (mixo) {
                         const dim3 g64((unsigned)((a.B + 63) / 64)), b64(64);
                         size_t lds_m = (long)g64.x <= (long)a.n_simd ? Stage<T>::lean_bytes(NJ) : Stage<T>::bytes(NJ);
@@ -3227,7 +3256,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                         else if (fun) VFIK_LAUNCH_MT(3, true);
                         else VFIK_LAUNCH_MT(3, false);
 #undef VFIK_LAUNCH_MT
-                        return;
+                        return true;
                     }
                     const size_t lds_funt = std::max(lds_lean, (size_t)(blk.x / 64) * (Stage<T>::lean_bytes(NJ) + 6 * Stage<T>::QSTEP));
                     if (lean1) {
@@ -3239,8 +3268,19 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
                         else if (uni) launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, true, false, DT>(a, grid, blk, lds_lean, stream);
                         else launch_full<T, NJ, NS, PL, false, true, 3, -1, false, false, false, false, DT>(a, grid, blk, lds_lean, stream);
                     }
-                    return;
+                    return true;
                 }
+                return false;
+            };
+            if constexpr (PAT) {
+                bool done = false;
+                const int opt = a.plain - 1;   // bit 0: shared tool, bit 1: shared IK weights
+                if (opt == 1) done = launch_opt(std::integral_constant<int, DHP | 2>());
+                if constexpr (NJ <= 7) {
+                    if (opt == 2) done = launch_opt(std::integral_constant<int, DHP | 4>());
+                    if (opt == 3) done = launch_opt(std::integral_constant<int, DHP | 6>());
+                }
+                if (done) return;
             }
             launch_v<T, NJ, NS, false, 0>(a_in, grid, blk, lds, stream, sub8);
             return;
@@ -3566,16 +3606,18 @@ double kconst_fill_t(void* dst, const vfik_chain& ch, const vfik_params& p, cons
     c.jp_kp = p.jp_kp;
     c.jp_delta = p.jp_delta;
     c.jl_gain = p.jl_gain;
-    // PLAIN variant of the kernel: revolute joints only, no trailing screw, unit weights.  *plain: 0 general variants, 1 PLAIN without a
-    // tool, 2 PLAIN with the batch's shared tool (the lean float32 kernels have variants that apply it -- cycle_body, TOOLC --, every other
-    // launch with a tool takes the general variants: launch_v).
+    // PLAIN variant of the kernel: revolute joints only, no trailing screw.  *plain: 0 general variants; else 1 + (the batch's shared tool
+    // is not the identity ? 1 : 0) + (its IK weights are not all one ? 2 : 0): the lean float32 kernels and the eight-lanes kernel have
+    // variants that apply a shared tool and shared weights themselves (cycle_body: TOOLC, WTSC), every other launch of such a handle takes
+    // the general variants (launch_v).
     bool pl = c.prismatic_mask == 0 && c.tail_c == 1.0 && c.tail_s == 0.0 && c.tail_e == 0.0;
     static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     bool tool_ident = true;
     for (int k = 0; k < 12; ++k) tool_ident = tool_ident && tool12[k] == ident[k];
-    for (int i = 0; i < 6; ++i) pl = pl && p.wy[i] == 1.0;
-    for (int i = 0; i < NJ; ++i) pl = pl && p.wq[i] == 1.0;
-    *plain = pl ? (tool_ident ? 1 : 2) : 0;
+    bool unit_w = true;
+    for (int i = 0; i < 6; ++i) unit_w = unit_w && p.wy[i] == 1.0;
+    for (int i = 0; i < NJ; ++i) unit_w = unit_w && p.wq[i] == 1.0;
+    *plain = pl ? 1 + (tool_ident ? 0 : 1) + (unit_w ? 0 : 2) : 0;
     bool base_i = true;
     {
         static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
