@@ -94,13 +94,17 @@ int vfik_set_fields(vfik_handle* h, int first_arm, int n_arms, const vfik_field*
 /* Per-arm IK weights: what each arm's vf process keeps after a /weight message (vf:164-179,295-309): 't' + 6
  * task-space weights -> wy[n_arms][6], 'j' + n joint-space weights -> wq[n_arms][n]; either may be NULL
  * (unchanged).  Arms never written use vfik_params.wy / wq; a later vfik_set_params that CHANGES wy or wq
- * is batch-wide again and replaces every arm's own weights. */
+ * is batch-wide again and replaces every arm's own weights.  A call for the WHOLE batch with both arrays whose rows are all equal is a
+ * batch-wide setting too (stored in the handle's parameters, the arms' own weights dropped): batch-wide weights keep the launches of an
+ * all-revolute chain of up to 7 joints on the kernels built for it, per-arm weights take the general variants. */
 int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double* wy, const double* wq);
 
 /* Per-arm mixer weights, w[n_arms][6]: what each arm's bridge keeps after a /bridge/weight message
  * (command_mixer.py:48-53; handlers send [cart, null, joint, 0], handlers.py:189-204).  NULL returns every
  * arm's weights to the batch-wide vfik_params.mix_w (per-arm limiter speeds of vfik_set_max_vel stay).  A
- * vfik_set_params that CHANGES vfik_params.mix_w writes the new weights to every arm. */
+ * vfik_set_params that CHANGES vfik_params.mix_w writes the new weights to every arm.  While every arm's bridge state (these weights and the
+ * limiter speed of vfik_set_max_vel) is the same, launches read it from the batch constants as if it had never been set per arm, and keep
+ * the kernel variants without per-arm options (every handler sends the same [cart, null, joint, 0] at start-up: handlers.py:189-204,481-497). */
 int vfik_set_mixer_weights(vfik_handle* h, int first_arm, int n_arms, const double* w);
 
 /* Per-arm limiter speed: what each arm's bridge keeps after a /bridge/max_vel message (bridge:612-623; the

@@ -227,3 +227,54 @@ def test_shared_weights_with_the_aux_block_and_differing_orders(env):
         ref = env.oc.cycle_batch(chain, params, w["q"], F, w["nfields"], tool=tool)
         _check(got, ref, 1e-6, want)
     eng.close()
+
+
+def test_equal_per_arm_weights_and_bridge_state_are_batch_wide(env):
+    """What the port layer produces when every arm's handlers send the same /weight and /bridge/weight (handlers.py:189-230,481-497): per-arm
+    arrays with equal rows.  The library stores them as the batch's (the DH-pattern kernels keep serving the launch; results are those of a
+    handle configured batch-wide, to the bit); one arm that differs brings the per-arm path back, and clearing it the batch-wide one."""
+    chain = env.robots.lwr()
+    B = 6000
+    f = env.abi
+    w = env.synth.make_workload(chain, B, 8, seed=59, io_dtype=np.float32)
+    wy = [1.0, 1.0, 1.0, 0.5, 0.5, 0.25]
+    wq = [1.0, 0.5, 1.0, 0.75, 1.0, 0.5, 1.0]
+    mw = [0.75, 0.5, 0.0, 0.0, 0.0, 0.0]
+    shared = f.default_params(flags=f.F_NULLSPACE | f.F_MIXER | f.F_LIMITER, wy=wy, wq=wq + [1.0] * 9, mix_w=mw, max_vel=0.25)   # (values exact in float32: the per-arm image holds them in the I/O type)
+    e0 = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=shared)
+    e0.set_fields(w["fields"], w["nfields"])
+    want = ("qdot_out", "qdot_null", "pose", "status")
+    base = e0.step_host(w["q"], want=want)
+    e0.close()
+    ref = env.oc.cycle_batch(chain, shared, w["q"], w["fields"], w["nfields"])
+    _check(base, ref, 1e-6, want)
+    eng = env.engine.Engine(chain, B, io_dtype=np.float32, max_slots=8, params=f.default_params(flags=f.F_NULLSPACE | f.F_MIXER | f.F_LIMITER))
+    eng.set_fields(w["fields"], w["nfields"])
+    eng.set_arm_weights(wy=np.tile(wy, (B, 1)), wq=np.tile(wq, (B, 1)))
+    eng.set_mixer_weights(np.tile(mw, (B, 1)))
+    eng.set_max_vel(np.full(B, 0.25))
+    assert eng.dh_pattern == 1
+    got = eng.step_host(w["q"], want=want)
+    for k in want:
+        assert np.array_equal(got[k], base[k]), k
+    # one arm with other joint weights and another mixer row: per arm again (the general variants), same numbers for every other arm
+    wq2 = np.tile(wq, (B, 1))
+    wq2[17] = [0.5] * 7
+    eng.set_arm_weights(wy=np.tile(wy, (B, 1)), wq=wq2)
+    mw2 = np.tile(mw, (B, 1))
+    mw2[99] = [0.02, 0.0, 0.0, 0.0, 0.0, 0.0]    # (small enough to stay under the limiter: otherwise only the direction would show)
+    eng.set_mixer_weights(mw2)
+    assert eng.dh_pattern == 0
+    got2 = eng.step_host(w["q"], want=want)
+    others = np.ones(B, bool)
+    others[[17, 99]] = False
+    assert np.abs(got2["qdot_out"][others] - base["qdot_out"][others]).max() < 1e-6
+    assert np.abs(got2["qdot_out"][17] - base["qdot_out"][17]).max() > 1e-4 and np.abs(got2["qdot_out"][99] - base["qdot_out"][99]).max() > 1e-4
+    # ... and back
+    eng.set_arm_weights(wy=np.tile(wy, (B, 1)), wq=np.tile(wq, (B, 1)))
+    eng.set_mixer_weights(np.tile(mw, (B, 1)))
+    assert eng.dh_pattern == 1
+    got3 = eng.step_host(w["q"], want=want)
+    for k in ("qdot_out", "pose", "status"):
+        assert np.array_equal(got3[k], base[k]), k
+    eng.close()

@@ -99,6 +99,11 @@ struct vfik_handle {
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     void* d_rollq[2] = {nullptr, nullptr};  // q ping-pong of the stepped rollout (long chains)
     double* d_wts = nullptr;    // per-arm IK weights [6 + n][Bpad], allocated by vfik_set_arm_weights
+    // every arm's bridge state (mixer weights, limiter speed) equal: the launch reads them from the batch constants like a handle that
+    // never had per-arm bridge state (a.mixw stays NULL, so the lean / publishing-lean variants keep serving it) -- what a port-level caller
+    // produces when every arm's handler sends the same /bridge/weight (handlers.py:189-204,481-497)
+    bool bridge_uniform = false;
+    double bridge_u[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... the common row, as the per-arm image holds it (rounded to the I/O type)
     double* d_track = nullptr;  // tracking-error history [38][B], allocated on first use
     void* d_mixw_arm = nullptr;  // per-arm mixer weights (2 quad planes), allocated on first use
     void* d_kconst = nullptr;  // vfik::KConst<n>: chain + parameters, read through the scalar cache
@@ -296,7 +301,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.tool = h->d_tool;
     a.null_control = io->null_control;
     a.ext = h->d_ext;
-    a.mixw = h->d_mixw_arm;
+    a.mixw = h->bridge_uniform ? nullptr : h->d_mixw_arm;
     a.q_ref = io->q_ref;
     a.q_cmded = io->q_cmded;
     a.lastvec = h->d_lastvec;
@@ -337,7 +342,12 @@ int upload_kconst(vfik_handle* h) {
     if (!h->chain_set) return VFIK_OK;
     std::vector<char> img(vfik::kconst_bytes(h->n));
     int plain = 0, dhp = 0;
-    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, h->params, h->tool_shared, &plain, &dhp);
+    vfik_params kp = h->params;
+    if (h->bridge_uniform) {   // (the arms' common bridge state stands in for the batch-wide values)
+        for (int k = 0; k < VFIK_MIX_CHANNELS; ++k) kp.mix_w[k] = h->bridge_u[k];
+        kp.max_vel = h->bridge_u[6];
+    }
+    const double err = vfik::kconst_fill(h->n, img.data(), h->chain, kp, h->tool_shared, &plain, &dhp);
     if (!(err < 1e-9)) return fail(VFIK_E_ARG, "chain: a fixed transform is not a rigid motion (DH recomposition error %.3e)", err);
     std::memcpy(img.data() + VFIK_KCONST_REP_SAFE_OFF(h->n), &h->uni_safe, sizeof(double));   // the batch's uniform repeller pair (vfik_set_fields)
     std::memcpy(img.data() + VFIK_KCONST_REP_FORCE_OFF, &h->uni_force, sizeof(double));
@@ -627,6 +637,24 @@ int vfik_set_arm_weights(vfik_handle* h, int first_arm, int n_arms, const double
             if (!std::isfinite(wq[(size_t)j * h->n + k])) return fail(VFIK_E_ARG, "arm %d: joint weight %d is not finite", first_arm + j, k);
     }
     HIP_TRY(hipSetDevice(h->device));
+    if (first_arm == 0 && n_arms == h->B && wy && wq) {
+        // The whole batch, and every arm with the same weights (a port-level caller forwards each arm's /weight bottle): these ARE batch-wide
+        // weights -- stored as such, the arms' own dropped, so that the launches stay on the kernels built for plain chains (WTSC) instead
+        // of the general variants.
+        bool same = true;
+        for (int j = 1; j < n_arms && same; ++j)
+            same = std::memcmp(wy + (size_t)j * 6, wy, 6 * sizeof(double)) == 0 && std::memcmp(wq + (size_t)j * h->n, wq, h->n * sizeof(double)) == 0;
+        if (same) {
+            for (int k = 0; k < 6; ++k) h->params.wy[k] = wy[k];
+            for (int k = 0; k < h->n; ++k) h->params.wq[k] = wq[k];
+            if (h->d_wts) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                (void)hipFree(h->d_wts);
+                h->d_wts = nullptr;
+            }
+            return upload_kconst(h);
+        }
+    }
     if (ensure_arm_weights(h) != VFIK_OK) return VFIK_E_HIP;
     const size_t Bp = h->Bpad;
     std::vector<double> row(n_arms);
@@ -818,6 +846,14 @@ static int upload_bridge_state(vfik_handle* h, int first_arm, int n_arms) {
     char* dst = static_cast<char*>(h->d_mixw_arm) + (size_t)first_arm * qb;
     HIP_TRY(hipMemcpy2DAsync(dst, plane, buf.data(), (size_t)n_arms * qb, (size_t)n_arms * qb, 2, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // all arms alike?  (O(B) per call; the callers are setters, not the cycle)
+    const bool was = h->bridge_uniform;
+    bool same = true;
+    for (int b = 1; b < h->B && same; ++b) same = std::memcmp(&h->bridge_host[(size_t)b * 8], &h->bridge_host[0], 7 * sizeof(double)) == 0;
+    h->bridge_uniform = same;
+    if (same)
+        for (int k = 0; k < 7; ++k) h->bridge_u[k] = h->io_dtype == 32 ? (double)(float)h->bridge_host[k] : h->bridge_host[k];
+    if (same || was) return upload_kconst(h);
     return VFIK_OK;
 }
 
