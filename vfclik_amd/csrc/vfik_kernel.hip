@@ -864,7 +864,7 @@ template <typename T, int NJ> struct ArenaLayout {
 template <typename T, int NJ, bool NULLSP, bool PLAIN, bool ROLL, bool FASTF, int LEAN, int CF, bool PERS, bool FUN, int WAVES, bool UNI, bool MIXO, int DHP>
 __device__ __forceinline__ void
 cycle_body(const typename std::conditional<SmallArgs<LEAN, ROLL, FASTF, MIXO>::value, KLean, KArgs>::type& a_in) {
-    static_assert(DHP == 0 || (PLAIN && FASTF && (!ROLL || LEAN == 1) && !PERS && LEAN != 0 && sizeof(T) == 4), "DHP: the lean straight-line float variants (single cycle, a stepped rollout's cycle, and the lean rollout)");
+    static_assert(DHP == 0 || (PLAIN && FASTF && (!ROLL || LEAN == 1) && !PERS && LEAN != 0 && (sizeof(T) == 4 || DHP == 1)), "DHP: the lean straight-line variants (single cycle, a stepped rollout's cycle, and the lean rollout); the option bits: float32 I/O");
     static_assert(!(DHP & 2) || LEAN != 2, "TOOLC: not in a stepped rollout's cycle");
     static_assert(!(DHP & 2) || !ROLL, "TOOLC: single-cycle variants only (a rollout with a tool is stepped)");
     // DHP bit 0: the chain's DH pattern (DhPattern<NJ, 1>); bit 1 (TOOLC): ONE tool for the whole batch, applied by the PLAIN kernel --
@@ -3094,13 +3094,17 @@ typename std::conditional<SmallArgs<LEAN, ROLL, FASTF>::value, KLean, KArgs>::ty
 // upper bits of fast_order (KLean's fourteen dwords are all taken).
 // The DH pattern a variant is built with: the requested one for the lean / publishing-lean single-cycle straight-line float variants and the lean rollout
 // (not the persistent one), none for every other variant -- so that asking for a pattern never multiplies the kernels of the rest.
-template <typename T, bool PL, bool ROLL, bool FASTF, int LEAN, bool PERS>
-constexpr int dhp_of(int dhp) { return (sizeof(T) == 4 && PL && FASTF && (ROLL ? LEAN == 1 : LEAN != 0) && !PERS) ? dhp : 0; }
+// float64 I/O (what a port-level caller's bottles are): the pattern alone, for the 7-joint chain (the LWR) -- C3's batch with float64 I/O
+// 6.12 -> 5.5 us; the shared-tool / shared-weights bits are float32-I/O only (launch_v).
+template <typename T, bool PL, bool ROLL, bool FASTF, int LEAN, bool PERS, int NJ>
+constexpr int dhp_of(int dhp) {
+    return (PL && FASTF && (ROLL ? LEAN == 1 : LEAN != 0) && !PERS) ? (sizeof(T) == 4 ? dhp : (NJ == 7 ? (dhp & 1) : 0)) : 0;
+}
 
 template <typename T, int NJ, bool NS, bool PL, int CF = -1, bool PERS = false, bool FUN = false, int WAVES = 1, bool UNI = false, int DHP = 0>
 void launch_lean(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
     // (the two-waves build on the compact image spilled 9 registers per lane with the pattern: it keeps the general DH form)
-    constexpr int D = (WAVES == 2 && !UNI) ? 0 : dhp_of<T, PL, false, true, 1, PERS>(DHP);
+    constexpr int D = (WAVES == 2 && !UNI) ? 0 : dhp_of<T, PL, false, true, 1, PERS, NJ>(DHP);
     KArgs a = a_in;
     if constexpr (UNI) a.fast_order = (a.fast_order & 255) | (a.uni_planes << 8);
     if constexpr (SmallArgs<1, false, true>::value && VFIK_SCALAR_KERNARG) {
@@ -3114,7 +3118,7 @@ void launch_lean(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t
 // Launch of any other variant: the prologue's arguments as scalars in front of the argument block, or the block alone
 template <typename T, int NJ, bool NS, bool PL, bool ROLL, bool FASTF, int LEAN, int CF = -1, bool PERS = false, bool FUN = false, bool UNI = false, bool MIXO = false, int DHP = 0>
 void launch_full(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t stream) {
-    constexpr int D = dhp_of<T, PL, ROLL, FASTF, LEAN, PERS>(DHP);
+    constexpr int D = dhp_of<T, PL, ROLL, FASTF, LEAN, PERS, NJ>(DHP);
     if constexpr (SmallArgs<LEAN, ROLL, FASTF, MIXO>::value) {
         launch_lean<T, NJ, NS, PL, CF, PERS, FUN, 1, UNI, DHP>(a_in, grid, blk, lds, stream);
     } else {
@@ -3295,7 +3299,7 @@ void launch_v(const KArgs& a_in, dim3 grid, dim3 blk, size_t lds, hipStream_t st
             lds_m += 1024;
             a.block = 64;
 #define VFIK_LAUNCH_M(LEANV, FUNV)                                                                                                              \
-    hipLaunchKernelGGL((cycle_kernel_m<T, NJ, NS, LEANV, FUNV, dhp_of<T, PL, false, true, LEANV, false>(DHP)>), g64, b64, lds_m, stream, (const void*)a.arena, a.q, a.qdot_out, a.active, a.orders, a.B, \
+    hipLaunchKernelGGL((cycle_kernel_m<T, NJ, NS, LEANV, FUNV, dhp_of<T, PL, false, true, LEANV, false, NJ>(DHP)>), g64, b64, lds_m, stream, (const void*)a.arena, a.q, a.qdot_out, a.active, a.orders, a.B, \
                        a.Bpad, a.slots_used, a.flags, a)
             if (lean1 && fun) VFIK_LAUNCH_M(1, true);
             else if (lean1) VFIK_LAUNCH_M(1, false);
