@@ -263,8 +263,8 @@ int vfik_memcpy_d2h(vfik_handle* h, void* dst_host, const void* src_dev, size_t 
 int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, float* ms_total);
 
 /* Small batches -- what vfclik itself runs is a handful of arms, each with its vf, nullspace and debug process and the bridge's
- * mixer (scripts/vfclik:88-105).  Launches the eight-lanes-per-arm kernel serves (revolute chain of up to 7 joints, identity tool,
- * unit weights, goal + integer-order decay repellers; with or without the nullspace module, joint-limit task, mixer, limiter,
+ * mixer (scripts/vfclik:88-105).  Launches the eight-lanes-per-arm kernel serves (revolute chain of up to 7 joints; no tool or ONE tool,
+ * and IK weights shared by the batch; goal + integer-order decay repellers; with or without the nullspace module, joint-limit task, mixer, limiter,
  * /control; outputs qdot_out, qdot_vf, qdot_null, pose, pose_nt, qdist, status; no gate, no per-arm limits or weights) take it
  * instead of one lane per arm up to the batch size where the same-box A/B stops winning (profiles/r03_latency_small_*.txt;
  * DESIGN.md section 5.8): 4096 arms when the per-cycle rows are published or without the nullspace module, 32 arms with the module
