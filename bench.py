@@ -165,7 +165,7 @@ def kernel_name(io_name, n, flags, batch, sub8, full=False, uni=True, dhp=0):
     ns = "true" if flags & 1 else "false"
     if sub8:
         return "vfik::cycle_sub8_kernel%s<%s,%d,%s,%d>" % ("" if flags & 1 else "_x", t, n, ns, dhp)
-    d = dhp if t == "float" else 0   # (the lane-per-arm pattern variants exist for float32 I/O)
+    d = dhp if (t == "float" or n == 7) else 0   # (the lane-per-arm pattern variants: float32 I/O; float64 I/O for the 7-joint chain)
     u = "true" if uni else "false"
     cf = flags if (flags & 1 and n <= 7 and flags in (5, 7)) else -1
     if full:  # the per-cycle rows asked for, no per-arm option: the publishing lean variant (LEAN 3)

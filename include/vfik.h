@@ -266,9 +266,9 @@ int vfik_time_steps(vfik_handle* h, const vfik_io* io, int warmup, int steps, fl
  * mixer (scripts/vfclik:88-105).  Launches the eight-lanes-per-arm kernel serves (revolute chain of up to 7 joints; no tool or ONE tool,
  * and IK weights shared by the batch; goal + integer-order decay repellers; with or without the nullspace module, joint-limit task, mixer, limiter,
  * /control; outputs qdot_out, qdot_vf, qdot_null, pose, pose_nt, qdist, status; no gate, no per-arm limits or weights) take it
- * instead of one lane per arm up to the batch size where the same-box A/B stops winning (profiles/r03_latency_small_*.txt;
- * DESIGN.md section 5.8): 4096 arms when the per-cycle rows are published or without the nullspace module, 32 arms with the module
- * and qdot_out alone.  vfik_set_small_batch_kernel sets ONE threshold for all three cases (0 = never; the environment variable
+ * instead of one lane per arm up to the batch size where the same-box A/B stops winning (profiles/r04_latency_small_*.txt;
+ * DESIGN.md section 5.8): 4096 arms when the per-cycle rows are published; launches that ask for qdot_out alone (with or without the
+ * nullspace module) stay on one lane per arm since round 4.  vfik_set_small_batch_kernel sets ONE threshold for all three cases (0 = never; the environment variable
  * VFIK_SUB8_MAX_BATCH does the same when the handle is created).  vfik_small_batch_launches: how many launches took that kernel
  * so far. */
 int vfik_set_small_batch_kernel(vfik_handle* h, int max_batch);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--dtype", default="float64")
     ap.add_argument("--nobs", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--sync", action="store_true", help="one launch + one synchronisation per cycle (what a control loop with fresh joint angles every cycle does) instead of back-to-back launches")
     a = ap.parse_args()
     import torch
     from vfclik_amd import _abi, engine, robots, synth
@@ -30,7 +31,7 @@ def main():
     dt = np.dtype(a.dtype).type
     tdt = torch.float32 if dt == np.float32 else torch.float64
     rows = []
-    print("7 joints, goal + %d repellers, %s I/O; us per launch" % (a.nobs, a.dtype))
+    print("7 joints, goal + %d repellers, %s I/O; us per %s" % (a.nobs, a.dtype, "cycle (launch + synchronisation, host clock)" if a.sync else "launch (back to back, HIP events)"))
     print("%6s %-8s %14s %16s %8s" % ("arms", "mode", "lane per arm", "8 lanes per arm", "ratio"))
     for B in (1, 8, 64, 512, 4096):
         w = synth.make_workload(chain, B, a.nobs, seed=3, io_dtype=dt)
@@ -49,7 +50,19 @@ def main():
             for name, mb in (("lane", 0), ("sub8", 1 << 30)):
                 eng.set_small_batch_kernel(mb)
                 n0 = eng.small_batch_launches
-                ts = [eng.time_steps(io, 50, 500) * 1e3 / 500 for _ in range(a.rounds)]
+                if a.sync:
+                    import time
+                    step = eng.stepper(io)
+                    ts = []
+                    for _ in range(a.rounds):
+                        for _ in range(50):
+                            step(); eng.sync()
+                        t0 = time.perf_counter()
+                        for _ in range(500):
+                            step(); eng.sync()
+                        ts.append((time.perf_counter() - t0) * 1e6 / 500)
+                else:
+                    ts = [eng.time_steps(io, 50, 500) * 1e3 / 500 for _ in range(a.rounds)]
                 took = eng.small_batch_launches > n0
                 res[name] = float(np.median(ts)) if (name == "lane" or took) else None
                 res[name + "_out"] = outs["qdot_out"].cpu().numpy().copy()

@@ -55,9 +55,12 @@ struct vfik_handle {
     // eight-lanes-per-arm kernel for lean launches of batches up to this size (vfik_set_small_batch_kernel,
     // VFIK_SUB8_MAX_BATCH).  Measured crossover (tools/ab_mapping.py, float64 I/O, goal + 4 repellers): 3-7 % faster than
     // one lane per arm up to 4 096 arms, equal at 8 192, 1.4x / 2.0x / 2.8x SLOWER at 16 384 / 32 768 / 65 536.
-    int sub8_max_batch = 4096;
-    int sub8_max_batch_ns = 32;      // with the nullspace module and qdot_out only: a handful of arms (-7 ... -11 %), even from 64 on
-    int sub8_max_batch_full = 4096;  // launches that publish the per-cycle rows: -18 ... -22 % at every size (vfik_set_small_batch_kernel sets all three)
+    // Round 4 re-decided the first two (profiles/r04_latency_small_*.txt): the lane-per-arm lean kernels lost a sixth of their instructions and
+    // enter through 56 bytes of scalar arguments, the eight-lanes kernel through the 360-byte block -- back to back it is the host's enqueue that
+    // sets its pace (3.5 against 4.9-6.1 us per lean launch at every size), and with one synchronisation per cycle the two are within 3 %.
+    int sub8_max_batch = 0;          // q -> qdot_out without the module: one lane per arm at every size (4096 until round 3)
+    int sub8_max_batch_ns = 0;       // with the nullspace module and qdot_out only: likewise (32 until round 3)
+    int sub8_max_batch_full = 4096;  // launches that publish the per-cycle rows: -4 ... -10 % at every size either way (vfik_set_small_batch_kernel sets all three)
     long sub8_launches = 0;  // how many launches took it (introspection for tests / A/B)
     long epoch = 0;          // moves with every call that can change what a launch bakes in (vfik_launch_epoch)
     int n_simd = 1024;       // 4 per CU of this device
