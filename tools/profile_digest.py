@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALG = {"C2": 512 * 4096, "C3": 384 * 65536, "C3N": 384 * 65536, "C5": 696 * 65536, "C3F": 600 * 65536, "C5F": 996 * 65536, "C2F": 944 * 4096}
-WAVES = {"C2": 4096 // 8, "C3": 1024, "C3N": 1024, "C5": 1024, "C3F": 1024, "C5F": 1024, "C2F": 4096 // 8}
+WAVES = {"C2": 4096 // 64, "C3": 1024, "C3N": 1024, "C5": 1024, "C3F": 1024, "C5F": 1024, "C2F": 4096 // 8}   # (C2: one lane per arm since round 4's end; 4096 // 8 before)
 
 
 def one(pattern):
