@@ -127,7 +127,7 @@ struct vfik_handle {
     std::vector<int> arm_order;  // per arm: -1 no repellers, n >= 0 all slots are repellers of integer order n, -2 general
     int slots_used = 0;
     int fast_order = 0;
-    int plain = 0;  // chain / weights allow the PLAIN kernel variant: 1 without a tool, 2 with the batch's shared tool (a run-time branch of those kernels)
+    int plain = 0;  // the chain allows the PLAIN kernel variants: 1 + (shared tool ? 1 : 0) + (shared IK weights other than one ? 2 : 0); 0: the general variants
     int dhp = 0;    // ... and the chain matches a DH pattern the lean kernels are built for (vfik_kernel.h: DhPattern)
     int dhp_allowed = 1;   // VFIK_DH_PATTERN=0: always the general DH form (tests, A/B)
     bool speed_set = false;
@@ -295,7 +295,7 @@ void fill_kargs(const vfik_handle* h, const vfik_io* io, vfik::KArgs& a) {
     a.fast_order = h->fast_order;
     a.flags = h->params.flags;
     a.tool_stride = h->tool_per_arm ? h->Bpad : 0;
-    a.plain = (h->plain && !h->tool_per_arm && !h->d_wts) ? h->plain : 0;   // (2: the PLAIN kernels with the shared tool)
+    a.plain = (h->plain && !h->tool_per_arm && !h->d_wts) ? h->plain : 0;   // (1 ... 4: the PLAIN kernels, with the batch's shared tool / shared IK weights as vfik_kernel.h says)
     a.wts = h->d_wts;
     a.q = io->q;
     a.goal = h->d_goal;

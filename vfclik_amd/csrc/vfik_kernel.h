@@ -118,7 +118,7 @@ struct KArgs {
                       // decay order (what object_feeder sends for point obstacles); -1: general path
     unsigned flags;
     int tool_stride;  // 0: one tool for the batch (KConst::tool); else per-arm tool quads ([3][Bpad])
-    int plain;        // 1: launch the PLAIN kernel variant (see vfik_kernel.hip); 2: PLAIN with the batch's shared tool (KConst::tool_on)
+    int plain;        // 0: the general variants; else the PLAIN kernels (vfik_kernel.hip), 1 + (the batch's shared tool is not the identity ? 1 : 0) + (its IK weights are not all one ? 2 : 0)
     int block;        // threads per block of the launch (read from here: blockDim.x costs its own scalar load)
     const void* q;
     const void* goal;
