@@ -439,3 +439,66 @@ def test_a_silent_arm_keeps_its_state_through_the_ports(net):
     assert np.abs(mb).max() > 0.1
     two.close()
     one.close()
+
+
+def test_a_fleet_configured_alike_through_the_handlers_keeps_the_pattern_kernels(net):
+    """Every arm's handlers send the same tool, the same IK weights and the same mixer weights (handlers.py:189-230) -- per-arm bottles on per-arm
+    ports.  The batch stays on the kernels built for the robot's chain (vfik_dh_pattern 1) and the results are the oracle's; one arm with
+    another hand takes the batch to the per-arm path (pattern 0), same results."""
+    yarp = net
+    from oracle import oracle_c
+    from vfclik_amd import _abi, robots
+    from vfclik_amd.handlers import HandleArmNew
+    from vfclik_amd.object_feeder import ObjectFeeder
+    from vfclik_amd.vf_module import ControlCycleBatch
+    chain = robots.lwr()
+    arms = ["/a%d" % k for k in range(3)]
+    bases = ["/0/lwr" + a for a in arms]
+    cc = ControlCycleBatch(chain, bases, io_dtype=np.float64)
+    feeders = [ObjectFeeder(b) for b in bases]
+    handles = [HandleArmNew(arm=a) for a in arms]
+    rng = np.random.default_rng(31)
+    q = rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (3, 7))
+    goals = chain.fk(rng.uniform(0.5 * chain.q_lo, 0.5 * chain.q_hi, (3, 7))).reshape(3, 16)
+    enc = [_open(yarp, "/sim%s/encoders" % a) for a in arms]
+    outs = [_open(yarp, "/probe%d/qdot" % k) for k in range(3)]
+    tool = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.2, 0, 0, 0, 1]
+    wq = [1, 0.5, 1, 0.5, 1, 0.25, 1]
+    for k, b in enumerate(bases):
+        yarp.Network.connect("/sim%s/encoders" % arms[k], b + "/vectorField/qIn")
+        yarp.Network.connect(b + "/vectorField/qdotOut", "/probe%d/qdot" % k)
+        handles[k].go_cart([float(x) for x in goals[k]])
+        handles[k].set_tool(tool)
+        handles[k].set_wik_joint_weights(wq)
+        handles[k].set_cartesian_control()       # /bridge/weight [1, 1, 0, 0] from every arm's handler (handlers.py:206-208)
+    for f in feeders:
+        f.spin_once()
+
+    def cycle_and_check(tools):
+        for k in range(3):
+            _send(enc[k], q[k])
+        assert cc.cycle().all()
+        for k in range(3):
+            p = _abi.default_params(flags=_abi.F_NULLSPACE | _abi.F_MIXER)
+            for i in range(7):
+                p.wq[i] = wq[i]
+            F = np.zeros((1, 1), dtype=_abi.FIELD_DTYPE)
+            F[0, 0]["id"], F[0, 0]["type"], F[0, 0]["force"] = 1, 1, 1.0
+            F[0, 0]["p"][:16] = goals[k]
+            F[0, 0]["p"][16] = 0.1
+            ref = oracle_c.cycle_batch(chain, p, q[k:k + 1], F, np.ones(1, dtype=np.int32), tool=np.asarray(tools[k], dtype=np.float64))
+            assert np.abs(_read(outs[k]) - ref["qdot_vf"][0]).max() < 1e-9, k
+
+    cycle_and_check([tool] * 3)
+    assert cc.engine.dh_pattern == 1, "equal per-arm settings must stay on the kernels built for the chain"
+    other = list(tool)
+    other[11] = 0.1
+    handles[2].set_tool(other)
+    cycle_and_check([tool, tool, other])
+    assert cc.engine.dh_pattern == 0
+    handles[2].set_tool(tool)
+    cycle_and_check([tool] * 3)
+    assert cc.engine.dh_pattern == 1
+    cc.close()
+    for f in feeders:
+        f.close()
